@@ -1,0 +1,39 @@
+"""Shared helpers for the parity tests (load goldens, build oracle problems)."""
+import os
+
+import numpy as np
+
+from oracle import fixtures
+from oracle import rhe_oracle as O
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+RHE_CASES = ["rhe_1bin_nocov", "rhe_3bin_nocov_rem", "rhe_3bin_cov", "rhe_1bin_missing",
+             "rhe_1bin_missing_mean", "rhe_1bin_n1024", "rhe_2bin_jn1", "rhe_1bin_2traits"]
+STREAMING_CASES = ["srhe_3bin_cov"]
+GENIE_CASES = ["genie_gxe_2bin", "genie_gxe_cov"]
+RESULT_KEYS_RHE = ["sigma_ests_total", "sig_errs", "h2_total", "h2_errs", "enrichment_total", "enrichment_errs",
+                   "h2_total_overlap", "h2_errs_overlap", "enrichment_total_overlap", "enrichment_errs_overlap"]
+RESULT_KEYS_GENIE = RESULT_KEYS_RHE[:6]
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+
+
+def oracle_problem(z, trait=0):
+    """Build the oracle's Problem from a golden file (inputs only + the reference's parsed covariates)."""
+    c = fixtures.cohort_from_npz(z)
+    miss = [int(i) for i in z["ref_missing_indv"]]
+    ph = np.delete(c.pheno.copy(), miss, axis=0)
+    ph = ph - np.mean(ph, axis=0)                      # base.py:153-154
+    cov = z["ref_cov_matrix"] if "ref_cov_matrix" in z else None
+    p = O.Problem(packed=c.packed, n_indv_orig=c.n_indv, annot=c.annot, pheno=ph[:, trait].reshape(-1, 1),
+                  n_jack=int(z["param_num_jack"]), k=int(z["param_num_random_vec"]), seed=int(z["param_seed"]),
+                  missing_indv=miss, cov=cov,
+                  impute=str(z["param_geno_impute_method"]) if "param_geno_impute_method" in z else "binary")
+    if "param_genie_model" in z:
+        p.genie_model = str(z["param_genie_model"])
+        p.env = c.env.reshape(-1, 1)
+    p.Z = O.make_probe_vectors(p.seed, p.n_indv, p.k)
+    return p, c

@@ -1,0 +1,80 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz, made by
+oracle/make_goldens.py in the build container).  Bit-exact on this torch build; the asserted
+tolerance (1e-9 relative) leaves room for a different BLAS on another host."""
+import numpy as np
+import pytest
+
+from oracle import rhe_oracle as O
+from tests.helpers import (GENIE_CASES, RESULT_KEYS_GENIE, RESULT_KEYS_RHE, RHE_CASES, STREAMING_CASES,
+                           load_golden, oracle_problem)
+
+RTOL = 1e-9
+
+
+def close(a, b, rtol=RTOL):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    scale = max(np.abs(b).max(), 1e-300)
+    return np.abs(a - b).max() <= rtol * scale
+
+
+@pytest.mark.parametrize("name", RHE_CASES)
+def test_rhe_nonstreaming(name):
+    z = load_golden(name)
+    n_traits = 2 if name.endswith("2traits") else 1
+    for t in range(n_traits):
+        p, _ = oracle_problem(z, trait=t)
+        assert np.array_equal(p.Z, z["ref_all_zb"])                      # probe vectors: same NumPy stream
+        st = O.precompute(p)
+        pre = f"ref_t{t}_"
+        assert np.array_equal(st.M, z[pre + "M"])                        # block indexing + bin counts: exact
+        blocks = np.stack([b.XXz for b in st.blocks], axis=1)
+        assert close(blocks, z[pre + "XXz_blocks"])
+        assert close(np.stack([b.yXXy for b in st.blocks], axis=1), z[pre + "yXXy_blocks"])
+        assert close(st.XXz[:, p.n_jack], z[pre + "XXz_total"])
+        assert close(st.yXXy[:, p.n_jack], z[pre + "yXXy_total"])
+        if p.cov is not None:
+            assert close(np.stack([b.XXUz for b in st.blocks], axis=1), z[pre + "XXUz_blocks"])
+            assert close(np.stack([b.UXXz for b in st.blocks], axis=1), z[pre + "UXXz_blocks"])
+        r = O.rhe_results(p, st)
+        assert close(r["T"], z[pre + "T"]) and close(r["q"], z[pre + "q"])
+        assert close(r["sigma_jack"], z[pre + "sigma_jack"])
+        for k in RESULT_KEYS_RHE:
+            assert close(r[k], z[pre + "res_" + k]), k
+
+
+@pytest.mark.parametrize("name", STREAMING_CASES)
+def test_rhe_streaming_bug_compatible(name):
+    """StreamingRHE(+cov, multiprocessing=True, num_workers=1): the only deterministic streaming mode."""
+    z = load_golden(name)
+    p, _ = oracle_problem(z)
+    st = O.precompute(p, streaming_compat=True)
+    assert np.array_equal(st.M, z["ref_t0_M"])
+    r = O.rhe_results(p, st)
+    assert close(r["sigma_jack"], z["ref_t0_sigma_jack"])
+    for k in RESULT_KEYS_RHE:
+        assert close(r[k], z["ref_t0_res_" + k]), k
+    # and it differs from the non-streaming ("fixed") semantics by the documented ~1 % (quirk Q4)
+    zf = load_golden("rhe_3bin_cov")
+    rel = np.abs(r["sigma_ests_total"] - zf["ref_t0_res_sigma_ests_total"]) / np.abs(zf["ref_t0_res_sigma_ests_total"])
+    assert 1e-4 < rel.max() < 0.1
+
+
+@pytest.mark.parametrize("name", GENIE_CASES)
+def test_genie_gxe(name):
+    z = load_golden(name)
+    p, _ = oracle_problem(z)
+    st = O.precompute(p)
+    assert np.array_equal(st.M, z["ref_t0_M"])
+    assert close(np.stack([b.XXz for b in st.blocks], axis=1), z["ref_t0_XXz_blocks"])
+    assert close(st.XXz[:, p.n_jack], z["ref_t0_XXz_total"])
+    assert close(st.yXXy[:, p.n_jack], z["ref_t0_yXXy_total"])
+    r = O.genie_results(p, st)
+    assert close(r["T"], z["ref_t0_T"])
+    for k in RESULT_KEYS_GENIE:
+        assert close(r[k], z["ref_t0_res_" + k]), k
+
+
+def test_block_range_matches_reference_rule():
+    # base.py:362-371: last block takes the remainder
+    assert [O.block_range(j, 247, 10) for j in (0, 8, 9)] == [(0, 24), (192, 216), (216, 247)]
+    assert O.distribute_work(100, 8) == [(0, 13), (13, 26), (26, 39), (39, 52), (52, 65), (65, 78), (78, 91), (91, 100)]
