@@ -1,0 +1,142 @@
+/*
+ * pyrhe_sketch.h -- C ABI of the MI355X (gfx950) streaming randomized-trace sketch engine.
+ *
+ * Drop-in boundary for ONE path of sriramlab/PyRHE: the per-jackknife-block sketch of
+ * StreamingBase (2-bit PLINK .bed decode -> per-SNP standardize -> X^T R and X (X^T R) per
+ * annotation bin).  The reference has no FFI; the Python seams these entry points replace are
+ * cited per function (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PYRHE_E* code or a positive hipError_t
+ *     otherwise; pyrhe_last_error() returns a thread-local message.  No exceptions cross the ABI.
+ *   - the caller owns every buffer; "device" pointers are HIP device memory of the engine's device.
+ *   - kernels are enqueued on the caller's stream (void* = hipStream_t) and never synchronise,
+ *     except where a function is documented as synchronous.
+ *   - one engine per GPU, driven from one host thread.
+ *
+ * Device data layout
+ *   packed genotypes : uint8 [n_rows][pitch], PLINK1 SNP-major rows (4 samples/byte, LSB first,
+ *                      code 00 -> 0, 10 -> 1, 11 -> 2 copies of allele 2, 01 -> missing), each row padded
+ *                      with zero bytes to `pitch` (a multiple of 256).  n_pad = 4 * pitch samples.
+ *   right-hand sides : float [n_cols][n_pad], one contiguous row per column (probe vectors Z, U Z,
+ *                      phenotype, e (.) Z ...); entries of dropped / padding samples must be 0.
+ *   sketch output    : float [nbin][n_sketch][n_pad].
+ */
+#ifndef PYRHE_SKETCH_H
+#define PYRHE_SKETCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYRHE_ABI_VERSION 1
+
+/* error codes (negative; positive values are hipError_t) */
+#define PYRHE_OK 0
+#define PYRHE_EINVAL (-1)   /* bad argument (message says which) */
+#define PYRHE_ENOMEM (-2)   /* workspace too small / allocation failed */
+#define PYRHE_ESTATE (-3)   /* call order (e.g. sketch before set_rhs) */
+
+/* precision modes: how the float32 operands R and W = D V are fed to the fp16 matrix cores */
+#define PYRHE_PREC_F16 0    /* one fp16 rounding (11 significant bits), 1 MFMA pass            */
+#define PYRHE_PREC_F16X2 1  /* hi + lo fp16 split (~22 significant bits), 2 MFMA passes        */
+
+/* column roles for pyrhe_engine_set_rhs */
+#define PYRHE_COL_SKETCH 1  /* gets both contractions: out[:, col] = X (X^T r)   (a7/a9 in SURVEY 8a) */
+#define PYRHE_COL_NORM 2    /* gets sum_s (x_s^T r)^2                            (a8)                 */
+
+#define PYRHE_MAX_COLS 30   /* sketch + norm columns (a ones column is appended internally)    */
+
+typedef struct pyrhe_engine pyrhe_engine_t;
+
+/* message of the last failing call on this thread */
+const char* pyrhe_last_error(void);
+int pyrhe_abi_version(void);
+
+/*
+ * Create an engine on `device` for cohorts of `n_keep` retained samples stored with row pitch
+ * `pitch` bytes.  `max_entries` bounds the SNPs of one (block, bin) list; `sub_snps` is the
+ * sub-block size (SNPs per kernel triple; 0 = default sized so a sub-block stays in the 256 MiB
+ * Infinity Cache between the two contractions).
+ * Replaces: Base._init_device / to_tensor device placement (pyrhe/src/base/base.py:195-206,
+ * pyrhe/src/util/mat_mul.py:4-15).   Synchronous (allocates).
+ */
+int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, int64_t max_entries, int precision,
+                        int64_t sub_snps, pyrhe_engine_t** out);
+int pyrhe_engine_destroy(pyrhe_engine_t* e);
+
+/*
+ * Install the right-hand columns.  R: device float [n_cols][n_pad]; role[c] in {SKETCH, NORM};
+ * keep: device float [n_pad] with 1 for retained samples and 0 for dropped / padding samples
+ * (it becomes the internal "ones" column that yields the exact integer genotype sums).
+ * Sketch columns must come first.  Builds fp16 MFMA-operand images, per-column power-of-two scales
+ * and column sums.   Replaces: to_tensor(all_zb / all_Uzb / pheno) in Base._compute_XXz/_XXUz/_yXXy
+ * (pyrhe/src/base/base.py:403-417; mat_mul.py:12 float32 cast).   Asynchronous on `stream`.
+ */
+int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int32_t* role_host, int n_cols,
+                         const float* keep, void* stream);
+
+/*
+ * Sketch one jackknife block.
+ *   packed      device uint8 [n_rows][pitch]  -- the block's SNP rows
+ *   entries     device int32 [offsets[nbin]]  -- row indices (0..n_rows-1) per bin, concatenated
+ *   offsets     HOST   int64 [nbin+1]
+ *   fill        device float [n_rows] or NULL -- value (0/1/2) substituted for missing calls of a SNP
+ *                                                (NULL: the block has no missing calls)
+ *   out_sketch  device float [nbin][n_sketch][n_pad]; accumulate != 0 adds to it, 0 overwrites
+ *   out_norm    device double [nbin][n_norm]        ; same accumulate flag
+ *   out_colsum  device int32 [offsets[nbin]] or NULL -- exact genotype sum per entry (after filling)
+ * Per bin b with entry list L_b and X_b the standardized genotypes of those SNPs
+ * (mu = mean, 1/sd = 1/sqrt(mu (1 - mu/2)), float32, pyrhe/src/base/base.py:291-296):
+ *   out_sketch[b][c][:] (+)= X_b (X_b^T R[c])      for the sketch columns
+ *   out_norm[b][c]      (+)= || X_b^T R[c] ||^2    for the norm columns
+ * Replaces, for one block: open_bed.read + 0<->2 flip (base.py:338-356), partition_bins (:325-336),
+ * standardize_geno (:291-296) and the k GEMV pairs of _compute_XXz/_compute_XXUz/_compute_yXXy
+ * (:403-417) as called from StreamingRHE.pre_compute_jackknife_bin(_pass_2)
+ * (pyrhe/src/models/rhe/streaming_rhe.py:13-43).   Asynchronous on `stream`.
+ */
+int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
+                              const int32_t* entries, const int64_t* offsets_host, int nbin,
+                              const float* fill, float* out_sketch, double* out_norm,
+                              int32_t* out_colsum, int accumulate, void* stream);
+
+/*
+ * Per-SNP statistics of a block, for the host-side imputation replay (Base.impute_geno,
+ * pyrhe/src/base/base.py:277-289): sum of observed genotypes and number of missing calls among the
+ * retained samples.  out_sum / out_nmiss: device int32 [n_rows].   Asynchronous on `stream`.
+ */
+int pyrhe_engine_block_stats(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
+                             int32_t* out_sum, int32_t* out_nmiss, void* stream);
+
+/*
+ * Decode rows to dense float32 [n_rows][n_pad] (count of allele 2, NaN = missing): the bit-exact
+ * decode contract of bed_reader.read + the reference's flip (base.py:338-356).  Test/diagnostic entry
+ * point; independent of any engine.   Asynchronous on `stream`.
+ */
+int pyrhe_decode_rows(const uint8_t* packed, int64_t n_rows, int64_t pitch, float* out, void* stream);
+
+/*
+ * Fill `packed` [n_rows][pitch] with synthetic genotypes: SNP (row0 + r) has allele frequency
+ * p = (13 + h(seed, row) % 116) / 256 and each sample two Bernoulli(p) draws from a counter-based
+ * hash keyed (seed, row, sample) -- regenerable row by row on the CPU (oracle/synth.py).
+ * Samples >= n_samples are padding (code 00).   Asynchronous on `stream`.
+ */
+int pyrhe_synth_genotypes(uint8_t* packed, int64_t n_rows, int64_t pitch, int64_t n_samples,
+                          uint64_t seed, int64_t row0, void* stream);
+
+/* engine introspection: 0 n_pad, 1 sub_snps, 2 n_tiles_in, 3 n_sketch, 4 n_norm, 5 workspace bytes */
+int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
+
+/* name + average device time (ms, from hipEvents on the launch stream) of the kernels of the last
+ * pyrhe_engine_sketch_block call made while profiling was enabled; see pyrhe_engine_profile(). */
+int pyrhe_engine_profile(pyrhe_engine_t* e, int enable);
+int pyrhe_engine_profile_read(pyrhe_engine_t* e, double* ms_gemm1, double* ms_mid, double* ms_gemm2,
+                              int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYRHE_SKETCH_H */

@@ -1,0 +1,940 @@
+// sketch_engine.hip -- MI355X (gfx950, CDNA4) streaming randomized-trace sketch engine.
+//
+// One jackknife block of PyRHE's StreamingBase hot loop, computed straight from the packed 2-bit
+// PLINK stream (reference: pyrhe/src/base/base.py:291-296,338-356,403-417 and
+// pyrhe/src/models/rhe/streaming_rhe.py:13-43; the C ABI is declared in include/pyrhe_sketch.h).
+//
+// The standardized matrix X is never materialised.  With G the raw allele counts (0/1/2),
+// mu_s = mean, d_s = 1/sqrt(mu_s (1 - mu_s/2)):
+//     X^T R = D (G^T R - mu (1^T R))          GEMM 1  (reduce over samples)   + rank-1 correction
+//     X  V  = G (D V) - 1 (mu^T D V)          GEMM 2  (reduce over SNPs)      + rank-1 correction
+// Both GEMMs run on v_mfma_f32_16x16x32_f16 with G decoded in registers (0/1/2 are exact in fp16),
+// float32 accumulation, and R / W = D V fed as fp16 (one rounding, or a hi+lo split).
+//
+// Kernels (per entry list = the SNP rows of one (block, bin, sub-block)):
+//   gemm1_kernel : P[e][c]   = sum_i G[i, row(e)] * Rh[i][c]        (+ exact column sums via a ones column)
+//   mid1_kernel  : mu, d, V = d (P/s - mu csum), norm columns -> sum V^2, W = d V (fp32) + column max
+//   mid2_kernel  : W -> fp16 MFMA operand image (per-column power-of-two scale), corr = mu^T Wh
+//   gemm2_kernel : out[c][i] (+)= keep[i] * (sum_e G[i, row(e)] * Wh[e][c] - corr[c]) / s_c
+//
+// MFMA operand maps used (guide: cdna_hip_programming.md section 3):
+//   A: lane l holds A[row l&15][k = 8 (l>>4) + j], j = 0..7;  B: lane l holds B[k = 8 (l>>4) + j][col l&15];
+//   D: lane l holds D[row 4 (l>>4) + r][col l&15], r = 0..3.
+// The k <-> sample/SNP assignment inside a fragment is a free permutation as long as both operands
+// agree, which is what makes a 1-instruction-per-register-pair unpack possible (see unpack()).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <stdarg.h>
+#include <algorithm>
+#include <vector>
+
+#include "../../include/pyrhe_sketch.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+union Frag {
+    half8 h;
+    uint32_t u[4];
+};
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail((int)_e, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                        __LINE__);                                                                \
+    } while (0)
+
+extern "C" const char* pyrhe_last_error(void) { return g_err; }
+extern "C" int pyrhe_abi_version(void) { return PYRHE_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+// PLINK code -> allele-2 count, 16 genotypes at once: 00->0, 10->1, 11->2 (and 01 "missing" -> 1):
+// value = code - (code >> 1).  No borrow crosses a crumb because code >= code >> 1.
+__device__ __forceinline__ uint32_t value_code(uint32_t w) { return w - ((w >> 1) & 0x55555555u); }
+// crumbs equal to 01 (missing call) -> 01 at that crumb, else 00
+__device__ __forceinline__ uint32_t missing_mask(uint32_t w) { return (~(w >> 1)) & w & 0x55555555u; }
+// substitute `fill` (0/1/2) for missing calls in a value-coded dword (missing currently decodes to 1)
+__device__ __forceinline__ uint32_t apply_fill(uint32_t v, uint32_t miss, int fill) {
+    return fill == 0 ? v - miss : (fill == 2 ? v + miss : v);
+}
+
+// Two genotypes -> one register of two exact fp16 values, for crumb position t = 0..3 of each 16-bit
+// half of x:  (x & (3 << 2t)) | 0x6400 is the fp16 number 1024 + c * 4^t (c lands in the mantissa);
+// one packed fma  h * 4^-t - 1024 * 4^-t  returns c exactly.
+template <int T>
+__device__ __forceinline__ uint32_t unpack(uint32_t x) {
+    constexpr uint32_t mask = 0x00030003u << (2 * T);
+    constexpr float sc = T == 0 ? 1.0f : (T == 1 ? 0.25f : (T == 2 ? 0.0625f : 0.015625f));
+    const uint32_t m = (x & mask) | 0x64006400u;
+    const half2v hx = __builtin_bit_cast(half2v, m);
+    const half2v s = {(_Float16)sc, (_Float16)sc};
+    const half2v b = {(_Float16)(-1024.0f * sc), (_Float16)(-1024.0f * sc)};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(hx, s, b));
+}
+// 8 genotypes (crumbs 0..3 of both 16-bit halves of x) -> MFMA operand fragment.
+// k-slot j of the fragment = crumb (j>>1) of half (j&1).
+__device__ __forceinline__ half8 unpack4(uint32_t x) {
+    Frag f;
+    f.u[0] = unpack<0>(x);
+    f.u[1] = unpack<1>(x);
+    f.u[2] = unpack<2>(x);
+    f.u[3] = unpack<3>(x);
+    return f.h;
+}
+
+__device__ __forceinline__ float pow2_scale(float maxabs) {
+    // largest power of two s with maxabs * s <= 8192 (fp16 max 65504); 1 for an all-zero column
+    if (!(maxabs > 0.0f) || !isfinite(maxabs)) return 1.0f;
+    int e;
+    frexpf(maxabs, &e);  // maxabs = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.0f, 13 - e);
+}
+
+// ------------------------------------------------------------------------------------------------
+// right-hand-side preparation
+// ------------------------------------------------------------------------------------------------
+__global__ void col_absmax_kernel(const float* __restrict__ R, int64_t n_pad, int n_cols,
+                                  uint32_t* __restrict__ colmax_bits) {
+    const int c = blockIdx.y;
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(R[(int64_t)c * n_pad + i]));
+    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(&colmax_bits[c], __float_as_uint(m));
+}
+
+// sample index of k-slot j of lane-group q in fragment (chunk, d, h) of GEMM 1
+__device__ __forceinline__ int64_t g1_sample(int64_t chunk, int d, int h, int q, int j) {
+    return chunk * 256 + q * 64 + d * 16 + (j & 1) * 8 + h * 4 + (j >> 1);
+}
+
+// Rfrag layout: [chunk][d 4][h 2][part][tile][lane 64][8 halves]; lane = q*16 + c
+template <int PARTS>
+__global__ void prep_rfrag_kernel(const float* __restrict__ R, const float* __restrict__ keep,
+                                  int64_t n_pad, int n_user_cols, int ntl,
+                                  const uint32_t* __restrict__ colmax_bits, float* __restrict__ scale,
+                                  half8* __restrict__ rfrag, double* __restrict__ csum) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = gid & 63;
+    int64_t rest = gid >> 6;
+    const int tile = rest % ntl;
+    rest /= ntl;
+    const int part = rest % PARTS;
+    rest /= PARTS;
+    const int h = rest & 1;
+    const int d = (rest >> 1) & 3;
+    const int64_t chunk = rest >> 3;
+    if (chunk * 256 >= n_pad) return;
+    const int c = tile * 16 + (lane & 15);
+    const int q = lane >> 4;
+    const bool is_ones = (c == n_user_cols);
+    float s = 1.0f;
+    if (c < n_user_cols) s = pow2_scale(__uint_as_float(colmax_bits[c]));
+    Frag f;
+    double acc = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        _Float16 v2[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = jj * 2 + b;
+            const int64_t i = g1_sample(chunk, d, h, q, j);
+            float x = 0.0f;
+            if (c < n_user_cols) x = R[(int64_t)c * n_pad + i] * s;
+            else if (is_ones) x = keep[i];
+            _Float16 hi = (_Float16)x;
+            _Float16 val = hi;
+            if (PARTS == 2 && part == 1) val = (_Float16)(x - (float)hi);
+            v2[b] = val;
+            acc += (double)(float)val;
+        }
+        half2v hv = {v2[0], v2[1]};
+        f.u[jj] = __builtin_bit_cast(uint32_t, hv);
+    }
+    rfrag[gid] = f.h;
+    // column sum of exactly the values the matrix cores will multiply (both parts summed)
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if (q == 0 && c <= n_user_cols) atomicAdd(&csum[c], acc);
+    if (chunk == 0 && d == 0 && h == 0 && part == 0 && q == 0) scale[c] = s;
+}
+
+// 2-bit keep mask (11 = retained sample) for the statistics kernel
+__global__ void prep_keepmask_kernel(const float* __restrict__ keep, int64_t n_pad, uint32_t* __restrict__ mask) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w * 16 >= n_pad) return;
+    uint32_t m = 0;
+    for (int t = 0; t < 16; ++t)
+        if (keep[w * 16 + t] != 0.0f) m |= 3u << (2 * t);
+    mask[w] = m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM 1:  P[e][c] = sum_i G[i, row(e)] * Rh[i][c]
+// workgroup = 4 waves, each wave owns 4 tiles of 16 entries (64 SNP rows) over one sample range.
+// ------------------------------------------------------------------------------------------------
+template <int NTL, int PARTS, bool MISSING>
+__global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
+                                                    const int32_t* __restrict__ rows, int n_entries,
+                                                    const float* __restrict__ fill,
+                                                    const half8* __restrict__ rfrag, int n_chunks,
+                                                    int chunks_per_split, float* __restrict__ P,
+                                                    int use_atomic) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int ebase = (blockIdx.x * 4 + wave) * 64;
+    if (ebase >= n_entries) return;
+    const int c0 = blockIdx.y * chunks_per_split;
+    const int c1 = min(c0 + chunks_per_split, n_chunks);
+
+    const uint8_t* rowp[4];
+    int fillv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int e = ebase + 16 * t + r;
+        e = e < n_entries ? e : n_entries - 1;
+        const int row = rows[e];
+        rowp[t] = packed + (int64_t)row * pitch + 16 * q;
+        fillv[t] = MISSING ? (int)fill[row] : 0;
+    }
+    float4v acc[4][NTL];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int n = 0; n < NTL; ++n) acc[t][n] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    for (int c = c0; c < c1; ++c) {
+        uint4 g[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g[t] = *reinterpret_cast<const uint4*>(rowp[t] + (int64_t)c * 64);
+        const half8* rf = rfrag + (int64_t)c * (8 * PARTS * NTL * 64) + lane;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t w = d == 0 ? g[t].x : (d == 1 ? g[t].y : (d == 2 ? g[t].z : g[t].w));
+                v[t] = value_code(w);
+                if (MISSING) v[t] = apply_fill(v[t], missing_mask(w), fillv[t]);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                half8 b[PARTS][NTL];
+#pragma unroll
+                for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+                    for (int n = 0; n < NTL; ++n) b[p][n] = rf[(((d * 2 + h) * PARTS + p) * NTL + n) * 64];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const half8 a = unpack4(h ? (v[t] >> 8) : v[t]);
+#pragma unroll
+                    for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+                        for (int n = 0; n < NTL; ++n)
+                            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[p][n], acc[t][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D: lane holds rows 4q + reg (entry), col r
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int n = 0; n < NTL; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int e = ebase + 16 * t + 4 * q + reg;
+                if (e < n_entries) {
+                    float* dst = P + (int64_t)e * (16 * NTL) + n * 16 + r;
+                    if (use_atomic) atomicAdd(dst, acc[t][n][reg]);
+                    else *dst = acc[t][n][reg];
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mid 1: per entry statistics, V = X^T R, norm accumulation, W = D V (float32) + column maxima
+// ------------------------------------------------------------------------------------------------
+__global__ void mid1_kernel(const float* __restrict__ P, int n_entries, int ncol_p, int n_sketch, int n_norm,
+                            const float* __restrict__ scale, const double* __restrict__ csum, float n_keep,
+                            float* __restrict__ mu_out, float* __restrict__ Wtmp,
+                            uint32_t* __restrict__ wmax_bits, double* __restrict__ norm_acc,
+                            int32_t* __restrict__ colsum_out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ones = n_sketch + n_norm;
+    float mu = 0.f, d = 0.f;
+    const bool live = e < n_entries;
+    if (live) {
+        const float sum = P[(int64_t)e * ncol_p + ones];   // exact integer (< 2^24)
+        // float32, the reference's operation order (base.py:292-293): mean; 1/sqrt(mean*(1-0.5*mean))
+        mu = sum / n_keep;
+        d = 1.0f / sqrtf(mu * (1.0f - 0.5f * mu));
+        mu_out[e] = mu;
+        if (colsum_out) colsum_out[e] = (int32_t)sum;
+    }
+    for (int c = 0; c < n_sketch + n_norm; ++c) {
+        float v = 0.f;
+        if (live) {
+            const double inv_s = 1.0 / (double)scale[c];
+            const double pc = (double)P[(int64_t)e * ncol_p + c] * inv_s;
+            v = (float)((double)d * (pc - (double)mu * (csum[c] * inv_s)));
+        }
+        if (c < n_sketch) {
+            float w = d * v;
+            if (live) Wtmp[(int64_t)e * n_sketch + c] = w;
+            float m = live ? fabsf(w) : 0.f;
+            for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+            if ((threadIdx.x & 63) == 0) atomicMax(&wmax_bits[c], __float_as_uint(m));
+        } else {
+            double s2 = live ? (double)v * (double)v : 0.0;
+            for (int off = 32; off; off >>= 1) s2 += __shfl_xor(s2, off);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&norm_acc[c - n_sketch], s2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mid 2: W -> fp16 operand image for GEMM 2 + rank-1 correction  corr[c] = sum_e mu_e * Wh[e][c]
+// Wfrag layout: [kb][part][tile][lane 64][8 halves]; lane = q*16 + c; element j <-> entry 32 kb + 8 q + j
+// ------------------------------------------------------------------------------------------------
+template <int PARTS>
+__global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restrict__ mu, int n_entries,
+                            int n_kb, int n_sketch, int nto, const uint32_t* __restrict__ wmax_bits,
+                            half8* __restrict__ wfrag, double* __restrict__ corr, float* __restrict__ wscale) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = gid & 63;
+    int64_t rest = gid >> 6;
+    const int tile = rest % nto;
+    rest /= nto;
+    const int part = rest % PARTS;
+    const int64_t kb = rest / PARTS;
+    if (kb >= n_kb) return;
+    const int c = tile * 16 + (lane & 15);
+    const int q = lane >> 4;
+    const float s = c < n_sketch ? pow2_scale(__uint_as_float(wmax_bits[c])) : 1.0f;
+    Frag f;
+    double acc = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        _Float16 v2[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int e = kb * 32 + q * 8 + jj * 2 + b;
+            float x = 0.f, m = 0.f;
+            if (e < n_entries && c < n_sketch) {
+                x = Wtmp[(int64_t)e * n_sketch + c] * s;
+                m = mu[e];
+            }
+            const _Float16 hi = (_Float16)x;
+            _Float16 val = hi;
+            if (PARTS == 2 && part == 1) val = (_Float16)(x - (float)hi);
+            v2[b] = val;
+            acc += (double)m * (double)(float)val;
+        }
+        half2v hv = {v2[0], v2[1]};
+        f.u[jj] = __builtin_bit_cast(uint32_t, hv);
+    }
+    wfrag[gid] = f.h;
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if (q == 0 && c < n_sketch) atomicAdd(&corr[c], acc);
+    if (kb == 0 && part == 0 && q == 0) wscale[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM 2:  out[c][i] (+)= keep[i] * ( sum_e G[i, row(e)] * Wh[e][c] - corr[c] ) / s_c
+// workgroup = 4 waves; a wave owns 256 samples (one 64-byte column group of the packed rows) and
+// walks the entry list 32 SNPs at a time: lane (n, q) reads dword n of rows 8q..8q+7.
+// ------------------------------------------------------------------------------------------------
+template <int NTO, int PARTS, bool MISSING>
+__global__ __launch_bounds__(256) void gemm2_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
+                                                    const int32_t* __restrict__ rows32, int n_kb,
+                                                    int kb_per_split, const float* __restrict__ fill,
+                                                    const half8* __restrict__ wfrag,
+                                                    const double* __restrict__ corr,
+                                                    const float* __restrict__ wscale,
+                                                    const float* __restrict__ keep, int n_sketch,
+                                                    int64_t n_pad, float* __restrict__ out, int mode) {
+    // mode: 0 store, 1 read-modify-write, 2 atomicAdd
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    if (grp * 256 >= n_pad) return;
+    const int kb0 = blockIdx.y * kb_per_split;
+    const int kb1 = min(kb0 + kb_per_split, n_kb);
+    const uint8_t* colp = packed + grp * 64 + n * 4;
+
+    float4v acc[NTO][16];
+#pragma unroll
+    for (int t = 0; t < NTO; ++t)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[t][u] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const int4* rp = reinterpret_cast<const int4*>(rows32 + (int64_t)kb * 32 + q * 8);
+        const int4 r0 = rp[0], r1 = rp[1];
+        const int rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(colp + (int64_t)rr[j] * pitch);
+            v[j] = value_code(w);
+            if (MISSING) v[j] = apply_fill(v[j], missing_mask(w), (int)fill[rr[j]]);
+        }
+        half8 a[PARTS][NTO];
+        const half8* wf = wfrag + (int64_t)kb * (PARTS * NTO * 64) + lane;
+#pragma unroll
+        for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) a[p][t] = wf[(p * NTO + t) * 64];
+        // x[p]: low halves of rows 2p (lo 16 bits) and 2p+1 (hi 16 bits) = samples 0..7 of the dword;
+        // y[p]: high halves = samples 8..15.
+        uint32_t x[4], y[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            x[p] = __builtin_amdgcn_perm(v[2 * p + 1], v[2 * p], 0x05040100u);
+            y[p] = __builtin_amdgcn_perm(v[2 * p + 1], v[2 * p], 0x07060302u);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            Frag f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                uint32_t src = (u & 8) ? y[p] : x[p];
+                if (u & 4) src >>= 8;
+                switch (u & 3) {
+                    case 0: f.u[p] = unpack<0>(src); break;
+                    case 1: f.u[p] = unpack<1>(src); break;
+                    case 2: f.u[p] = unpack<2>(src); break;
+                    default: f.u[p] = unpack<3>(src); break;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+                for (int t = 0; t < NTO; ++t)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[p][t], f.h, acc[t][u], 0, 0, 0);
+        }
+    }
+    // D[row = column c = 4q + reg][col = n]; for MFMA u the sample is 256 grp + 16 n + u:
+    // a lane owns 16 consecutive samples per (tile, reg).
+    const int64_t i0 = grp * 256 + n * 16;
+    float kp[16];
+#pragma unroll
+    for (int u4 = 0; u4 < 4; ++u4) {
+        const float4 k4 = *reinterpret_cast<const float4*>(keep + i0 + 4 * u4);
+        kp[4 * u4] = k4.x; kp[4 * u4 + 1] = k4.y; kp[4 * u4 + 2] = k4.z; kp[4 * u4 + 3] = k4.w;
+    }
+#pragma unroll
+    for (int t = 0; t < NTO; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int c = t * 16 + 4 * q + reg;
+            if (c >= n_sketch) continue;
+            const float cr = blockIdx.y == 0 ? (float)corr[c] : 0.f;
+            const float inv = 1.0f / wscale[c];
+            float* dst = out + (int64_t)c * n_pad + i0;
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                float4 val;
+                val.x = (acc[t][4 * u4 + 0][reg] - cr) * inv * kp[4 * u4 + 0];
+                val.y = (acc[t][4 * u4 + 1][reg] - cr) * inv * kp[4 * u4 + 1];
+                val.z = (acc[t][4 * u4 + 2][reg] - cr) * inv * kp[4 * u4 + 2];
+                val.w = (acc[t][4 * u4 + 3][reg] - cr) * inv * kp[4 * u4 + 3];
+                float4* d4 = reinterpret_cast<float4*>(dst + 4 * u4);
+                if (mode == 0) {
+                    *d4 = val;
+                } else if (mode == 1) {
+                    float4 o = *d4;
+                    o.x += val.x; o.y += val.y; o.z += val.z; o.w += val.w;
+                    *d4 = o;
+                } else {
+                    atomicAdd(dst + 4 * u4 + 0, val.x);
+                    atomicAdd(dst + 4 * u4 + 1, val.y);
+                    atomicAdd(dst + 4 * u4 + 2, val.z);
+                    atomicAdd(dst + 4 * u4 + 3, val.w);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------------------
+// pad an entry sub-list to a multiple of 32 (pad rows read row rows[0]; their W is zero)
+__global__ void pad_rows_kernel(const int32_t* __restrict__ rows, int n, int n_pad32, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pad32) out[i] = i < n ? rows[i] : rows[0];
+}
+
+__global__ void block_stats_kernel(const uint8_t* __restrict__ packed, int64_t pitch, int64_t n_rows,
+                                   const uint32_t* __restrict__ keepmask, int32_t* __restrict__ out_sum,
+                                   int32_t* __restrict__ out_nmiss) {
+    // one wave per row
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t* rp = reinterpret_cast<const uint32_t*>(packed + row * pitch);
+    int sum = 0, nm = 0;
+    for (int64_t w = lane; w < pitch / 4; w += 64) {
+        const uint32_t km = keepmask[w];
+        const uint32_t x = rp[w] & km;
+        const uint32_t miss = missing_mask(x);
+        const uint32_t v = value_code(x) - miss;   // missing -> 0
+        sum += __popc(v & 0x55555555u) + 2 * __popc(v & 0xAAAAAAAAu);
+        nm += __popc(miss);
+    }
+    for (int off = 32; off; off >>= 1) {
+        sum += __shfl_xor(sum, off);
+        nm += __shfl_xor(nm, off);
+    }
+    if (lane == 0) {
+        out_sum[row] = sum;
+        out_nmiss[row] = nm;
+    }
+}
+
+__global__ void decode_rows_kernel(const uint8_t* __restrict__ packed, int64_t n_rows, int64_t pitch,
+                                   float* __restrict__ out) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per byte
+    if (gid >= n_rows * pitch) return;
+    const uint32_t b = packed[gid];
+    float4 o;
+    float* po = &o.x;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t code = (b >> (2 * t)) & 3u;
+        po[t] = code == 1 ? __builtin_nanf("") : (float)(code - (code >> 1));
+    }
+    reinterpret_cast<float4*>(out)[gid] = o;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// one thread per dword (16 samples); see oracle/synth.py for the CPU twin
+__global__ void synth_kernel(uint8_t* __restrict__ packed, int64_t n_rows, int64_t pitch, int64_t n_samples,
+                             uint64_t seed, int64_t row0) {
+    const int64_t words = pitch / 4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_rows * words) return;
+    const int64_t r = gid / words, w = gid % words;
+    const uint64_t row = (uint64_t)(row0 + r);
+    const uint32_t thr = 13u + (uint32_t)(mix64(seed * 0x9E3779B97F4A7C15ull + row * 0xD1B54A32D192ED03ull) % 116ull);
+    const uint64_t base = seed * 0x9E3779B97F4A7C15ull + row * 0xD1B54A32D192ED03ull + ((uint64_t)w + 1) * 0x8CB92BA72F3D8DD7ull;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t h = mix64(base + (uint64_t)(k + 1) * 0x9E3779B97F4A7C15ull);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t a = (uint32_t)(h >> (16 * t)) & 0xFFu;
+            const uint32_t b = (uint32_t)(h >> (16 * t + 8)) & 0xFFu;
+            const uint32_t g = (a < thr) + (b < thr);
+            const int64_t smp = w * 16 + k * 4 + t;
+            const uint32_t code = smp < n_samples ? (g == 0 ? 0u : (g == 1 ? 2u : 3u)) : 0u;
+            out |= code << (2 * (k * 4 + t));
+        }
+    }
+    reinterpret_cast<uint32_t*>(packed)[gid] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------------
+struct pyrhe_engine {
+    int device = 0;
+    int64_t n_keep = 0, pitch = 0, n_pad = 0, max_entries = 0, sub_snps = 0;
+    int precision = 0, parts = 1;
+    int n_sketch = 0, n_norm = 0, n_user = 0, ntl = 0, nto = 0;
+    bool rhs_set = false;
+    // device buffers
+    half8* rfrag = nullptr;
+    size_t rfrag_bytes = 0;
+    float* rscale = nullptr;      // [16*ntl_max]
+    double* csum = nullptr;       // [16*ntl_max]
+    uint32_t* colmax = nullptr;   // [16*ntl_max]
+    uint32_t* keepmask = nullptr; // [n_pad/16]
+    float* keep = nullptr;        // [n_pad] private copy
+    // per sub-block workspace (one zeroed region first: P | wmax | corr | normacc)
+    uint8_t* ws = nullptr;
+    size_t ws_bytes = 0, zero_bytes = 0;
+    float* P = nullptr;
+    uint32_t* wmax = nullptr;
+    double* corr = nullptr;
+    double* normacc = nullptr;
+    float* mu = nullptr;
+    float* Wtmp = nullptr;
+    float* wscale = nullptr;
+    half8* wfrag = nullptr;
+    int32_t* rows32 = nullptr;
+    // profiling
+    bool profile = false;
+    struct Ev { int kind; hipEvent_t a, b; };
+    std::vector<Ev> evs;
+    size_t total_bytes = 0;
+};
+
+static constexpr int kMaxTiles = 2;  // 32 logical columns
+
+extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, int64_t max_entries, int precision,
+                                   int64_t sub_snps, pyrhe_engine_t** out) {
+    if (!out) return fail(PYRHE_EINVAL, "out is NULL");
+    if (pitch <= 0 || pitch % 256) return fail(PYRHE_EINVAL, "pitch (%lld) must be a positive multiple of 256", (long long)pitch);
+    if (n_keep <= 0 || n_keep > 4 * pitch) return fail(PYRHE_EINVAL, "n_keep (%lld) must be in 1..4*pitch", (long long)n_keep);
+    if (n_keep >= (1 << 23)) return fail(PYRHE_EINVAL, "n_keep (%lld) >= 2^23: genotype sums would not be exact in float32", (long long)n_keep);
+    if (precision != PYRHE_PREC_F16 && precision != PYRHE_PREC_F16X2) return fail(PYRHE_EINVAL, "unknown precision %d", precision);
+    if (max_entries <= 0) return fail(PYRHE_EINVAL, "max_entries must be positive");
+    HIPCHK(hipSetDevice(device));
+    auto* e = new pyrhe_engine();
+    e->device = device;
+    e->n_keep = n_keep;
+    e->pitch = pitch;
+    e->n_pad = 4 * pitch;
+    e->precision = precision;
+    e->parts = precision == PYRHE_PREC_F16X2 ? 2 : 1;
+    if (sub_snps <= 0) {
+        // keep one sub-block (<= 96 MiB of packed rows) resident in the 256 MiB Infinity Cache between GEMM 1 and GEMM 2
+        sub_snps = (int64_t)(96ll << 20) / pitch;
+        if (sub_snps < 64) sub_snps = 64;
+    }
+    sub_snps = (sub_snps + 31) / 32 * 32;
+    if (sub_snps > max_entries) sub_snps = (max_entries + 31) / 32 * 32;
+    e->sub_snps = sub_snps;
+    e->max_entries = max_entries;
+    const int ncolmax = 16 * kMaxTiles;
+    e->rfrag_bytes = (size_t)e->n_pad * ncolmax * e->parts * sizeof(_Float16);
+    HIPCHK(hipMalloc(&e->rfrag, e->rfrag_bytes));
+    HIPCHK(hipMalloc(&e->rscale, ncolmax * sizeof(float)));
+    HIPCHK(hipMalloc(&e->csum, ncolmax * sizeof(double)));
+    HIPCHK(hipMalloc(&e->colmax, ncolmax * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&e->keepmask, e->n_pad / 16 * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&e->keep, e->n_pad * sizeof(float)));
+    // workspace
+    const size_t S = (size_t)sub_snps;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t oP = carve(S * ncolmax * sizeof(float));
+    const size_t oWmax = carve(ncolmax * sizeof(uint32_t));
+    const size_t oCorr = carve(ncolmax * sizeof(double));
+    const size_t oNorm = carve(ncolmax * sizeof(double));
+    e->zero_bytes = off;
+    const size_t oMu = carve(S * sizeof(float));
+    const size_t oWtmp = carve(S * ncolmax * sizeof(float));
+    const size_t oWscale = carve(ncolmax * sizeof(float));
+    const size_t oWfrag = carve((S / 32) * e->parts * kMaxTiles * 64 * sizeof(half8));
+    const size_t oRows = carve(S * sizeof(int32_t));
+    e->ws_bytes = off;
+    HIPCHK(hipMalloc(&e->ws, e->ws_bytes));
+    e->P = (float*)(e->ws + oP);
+    e->wmax = (uint32_t*)(e->ws + oWmax);
+    e->corr = (double*)(e->ws + oCorr);
+    e->normacc = (double*)(e->ws + oNorm);
+    e->mu = (float*)(e->ws + oMu);
+    e->Wtmp = (float*)(e->ws + oWtmp);
+    e->wscale = (float*)(e->ws + oWscale);
+    e->wfrag = (half8*)(e->ws + oWfrag);
+    e->rows32 = (int32_t*)(e->ws + oRows);
+    e->total_bytes = e->ws_bytes + e->rfrag_bytes + e->n_pad * 4 + e->n_pad / 4;
+    *out = e;
+    return PYRHE_OK;
+}
+
+extern "C" int pyrhe_engine_destroy(pyrhe_engine_t* e) {
+    if (!e) return PYRHE_OK;
+    hipSetDevice(e->device);
+    for (auto& ev : e->evs) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    hipFree(e->rfrag); hipFree(e->rscale); hipFree(e->csum); hipFree(e->colmax);
+    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->ws);
+    delete e;
+    return PYRHE_OK;
+}
+
+extern "C" int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what) {
+    if (!e) return -1;
+    switch (what) {
+        case 0: return e->n_pad;
+        case 1: return e->sub_snps;
+        case 2: return e->ntl;
+        case 3: return e->n_sketch;
+        case 4: return e->n_norm;
+        case 5: return (int64_t)e->total_bytes;
+        default: return -1;
+    }
+}
+
+extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int32_t* role_host, int n_cols,
+                                    const float* keep, void* stream_) {
+    if (!e || !R || !role_host || !keep) return fail(PYRHE_EINVAL, "NULL argument");
+    if (n_cols < 1 || n_cols > PYRHE_MAX_COLS) return fail(PYRHE_EINVAL, "n_cols %d outside 1..%d", n_cols, PYRHE_MAX_COLS);
+    int ns = 0, nn = 0;
+    for (int c = 0; c < n_cols; ++c) {
+        if (role_host[c] == PYRHE_COL_SKETCH) {
+            if (nn) return fail(PYRHE_EINVAL, "sketch columns must precede norm columns (column %d)", c);
+            ++ns;
+        } else if (role_host[c] == PYRHE_COL_NORM) {
+            ++nn;
+        } else {
+            return fail(PYRHE_EINVAL, "role[%d] = %d is not SKETCH/NORM", c, role_host[c]);
+        }
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipSetDevice(e->device));
+    e->n_sketch = ns;
+    e->n_norm = nn;
+    e->n_user = n_cols;
+    e->ntl = (n_cols + 1 + 15) / 16;
+    e->nto = ns ? (ns + 15) / 16 : 1;
+    if (e->ntl > kMaxTiles) return fail(PYRHE_EINVAL, "too many columns");
+    HIPCHK(hipMemcpyAsync(e->keep, keep, e->n_pad * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemsetAsync(e->colmax, 0, 16 * kMaxTiles * sizeof(uint32_t), stream));
+    HIPCHK(hipMemsetAsync(e->csum, 0, 16 * kMaxTiles * sizeof(double), stream));
+    {
+        dim3 grid((unsigned)std::min<int64_t>((e->n_pad + 255) / 256, 1024), n_cols);
+        col_absmax_kernel<<<grid, 256, 0, stream>>>(R, e->n_pad, n_cols, e->colmax);
+    }
+    {
+        const int64_t threads = (e->n_pad / 256) * 8 * e->parts * e->ntl * 64;
+        const unsigned grid = (unsigned)((threads + 255) / 256);
+        if (e->parts == 2)
+            prep_rfrag_kernel<2><<<grid, 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale, e->rfrag, e->csum);
+        else
+            prep_rfrag_kernel<1><<<grid, 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale, e->rfrag, e->csum);
+    }
+    {
+        const int64_t words = e->n_pad / 16;
+        prep_keepmask_kernel<<<(unsigned)((words + 255) / 256), 256, 0, stream>>>(e->keep, e->n_pad, e->keepmask);
+    }
+    HIPCHK(hipGetLastError());
+    e->rhs_set = true;
+    return PYRHE_OK;
+}
+
+// ---- launch helpers --------------------------------------------------------------------------
+struct ProfScope {
+    pyrhe_engine* e;
+    hipStream_t s;
+    int kind;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(pyrhe_engine* e_, hipStream_t s_, int kind_) : e(e_), s(s_), kind(kind_) {
+        if (e->profile) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, s);
+        }
+    }
+    ~ProfScope() {
+        if (e->profile) {
+            hipEventRecord(b, s);
+            e->evs.push_back({kind, a, b});
+        }
+    }
+};
+
+template <int NTL, int PARTS>
+static void launch_gemm1(pyrhe_engine* e, const uint8_t* packed, const int32_t* rows, int n, const float* fill,
+                         int n_chunks, int cps, int splits, hipStream_t stream) {
+    dim3 grid((n + 255) / 256, splits);
+    if (fill)
+        gemm1_kernel<NTL, PARTS, true><<<grid, 256, 0, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_chunks, cps, e->P, splits > 1);
+    else
+        gemm1_kernel<NTL, PARTS, false><<<grid, 256, 0, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_chunks, cps, e->P, splits > 1);
+}
+
+template <int NTO, int PARTS>
+static void launch_gemm2(pyrhe_engine* e, const uint8_t* packed, int n_kb, int kbps, int splits, const float* fill,
+                         float* out, int mode, hipStream_t stream) {
+    dim3 grid((unsigned)(e->n_pad / 1024), splits);
+    if (fill)
+        gemm2_kernel<NTO, PARTS, true><<<grid, 256, 0, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode);
+    else
+        gemm2_kernel<NTO, PARTS, false><<<grid, 256, 0, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode);
+}
+
+__global__ void add_norm_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, int accumulate) {
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
+}
+
+extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
+                                         const int32_t* entries, const int64_t* offsets_host, int nbin,
+                                         const float* fill, float* out_sketch, double* out_norm,
+                                         int32_t* out_colsum, int accumulate, void* stream_) {
+    if (!e || !packed || !offsets_host) return fail(PYRHE_EINVAL, "NULL argument");
+    if (!e->rhs_set) return fail(PYRHE_ESTATE, "pyrhe_engine_set_rhs has not been called");
+    if (nbin < 1) return fail(PYRHE_EINVAL, "nbin must be >= 1");
+    if (n_rows < 0) return fail(PYRHE_EINVAL, "n_rows negative");
+    if (e->n_sketch && !out_sketch) return fail(PYRHE_EINVAL, "out_sketch is NULL but there are sketch columns");
+    if (e->n_norm && !out_norm) return fail(PYRHE_EINVAL, "out_norm is NULL but there are norm columns");
+    for (int b = 0; b < nbin; ++b) {
+        if (offsets_host[b + 1] < offsets_host[b]) return fail(PYRHE_EINVAL, "offsets not monotone at bin %d", b);
+        if (offsets_host[b + 1] - offsets_host[b] > e->max_entries)
+            return fail(PYRHE_EINVAL, "bin %d has %lld entries > max_entries %lld", b,
+                        (long long)(offsets_host[b + 1] - offsets_host[b]), (long long)e->max_entries);
+    }
+    if (offsets_host[nbin] > 0 && !entries) return fail(PYRHE_EINVAL, "entries is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipSetDevice(e->device));
+    const int n_chunks = (int)(e->pitch / 64);
+    const int ncol_p = 16 * e->ntl;
+    const int64_t sk_stride = (int64_t)e->n_sketch * e->n_pad;
+
+    for (int b = 0; b < nbin; ++b) {
+        const int64_t n_b = offsets_host[b + 1] - offsets_host[b];
+        float* outb = out_sketch ? out_sketch + b * sk_stride : nullptr;
+        double* normb = out_norm ? out_norm + (int64_t)b * e->n_norm : nullptr;
+        if (n_b == 0) {
+            if (!accumulate) {
+                if (outb) HIPCHK(hipMemsetAsync(outb, 0, sk_stride * sizeof(float), stream));
+                if (normb && e->n_norm) HIPCHK(hipMemsetAsync(normb, 0, e->n_norm * sizeof(double), stream));
+            }
+            continue;
+        }
+        bool first = true;
+        for (int64_t s0 = 0; s0 < n_b; s0 += e->sub_snps) {
+            const int n = (int)std::min<int64_t>(e->sub_snps, n_b - s0);
+            const int32_t* rows = entries + offsets_host[b] + s0;
+            const int n32 = (n + 31) / 32 * 32;
+            const int n_kb = n32 / 32;
+            HIPCHK(hipMemsetAsync(e->ws, 0, e->zero_bytes, stream));
+            pad_rows_kernel<<<(n32 + 255) / 256, 256, 0, stream>>>(rows, n, n32, e->rows32);
+            // ---- GEMM 1
+            {
+                const int gx = (n + 255) / 256;
+                int splits = (768 + gx - 1) / gx;
+                splits = std::max(1, std::min(splits, n_chunks / 8 > 0 ? n_chunks / 8 : 1));
+                const int cps = (n_chunks + splits - 1) / splits;
+                splits = (n_chunks + cps - 1) / cps;
+                ProfScope ps(e, stream, 0);
+                if (e->ntl == 1 && e->parts == 1) launch_gemm1<1, 1>(e, packed, rows, n, fill, n_chunks, cps, splits, stream);
+                else if (e->ntl == 1 && e->parts == 2) launch_gemm1<1, 2>(e, packed, rows, n, fill, n_chunks, cps, splits, stream);
+                else if (e->ntl == 2 && e->parts == 1) launch_gemm1<2, 1>(e, packed, rows, n, fill, n_chunks, cps, splits, stream);
+                else launch_gemm1<2, 2>(e, packed, rows, n, fill, n_chunks, cps, splits, stream);
+            }
+            // ---- mid
+            {
+                ProfScope ps(e, stream, 1);
+                mid1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
+                                                                 (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->normacc,
+                                                                 out_colsum ? out_colsum + offsets_host[b] + s0 : nullptr);
+                if (e->n_sketch) {
+                    const int64_t threads = (int64_t)n_kb * e->parts * e->nto * 64;
+                    const unsigned grid = (unsigned)((threads + 255) / 256);
+                    if (e->parts == 2) mid2_kernel<2><<<grid, 256, 0, stream>>>(e->Wtmp, e->mu, n, n_kb, e->n_sketch, e->nto, e->wmax, e->wfrag, e->corr, e->wscale);
+                    else mid2_kernel<1><<<grid, 256, 0, stream>>>(e->Wtmp, e->mu, n, n_kb, e->n_sketch, e->nto, e->wmax, e->wfrag, e->corr, e->wscale);
+                }
+                if (e->n_norm) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc, normb, e->n_norm, accumulate || !first);
+            }
+            // ---- GEMM 2
+            if (e->n_sketch) {
+                const int gx = (int)(e->n_pad / 1024);
+                int splits = gx >= 256 ? 1 : (512 + gx - 1) / gx;
+                splits = std::max(1, std::min(splits, n_kb));
+                const int kbps = (n_kb + splits - 1) / splits;
+                splits = (n_kb + kbps - 1) / kbps;
+                int mode;
+                const bool acc_now = accumulate || !first;
+                if (splits > 1) {
+                    if (!acc_now) HIPCHK(hipMemsetAsync(outb, 0, sk_stride * sizeof(float), stream));
+                    mode = 2;
+                } else {
+                    mode = acc_now ? 1 : 0;
+                }
+                ProfScope ps(e, stream, 2);
+                if (e->nto == 1 && e->parts == 1) launch_gemm2<1, 1>(e, packed, n_kb, kbps, splits, fill, outb, mode, stream);
+                else if (e->nto == 1 && e->parts == 2) launch_gemm2<1, 2>(e, packed, n_kb, kbps, splits, fill, outb, mode, stream);
+                else if (e->nto == 2 && e->parts == 1) launch_gemm2<2, 1>(e, packed, n_kb, kbps, splits, fill, outb, mode, stream);
+                else launch_gemm2<2, 2>(e, packed, n_kb, kbps, splits, fill, outb, mode, stream);
+            }
+            first = false;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
+extern "C" int pyrhe_engine_block_stats(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
+                                        int32_t* out_sum, int32_t* out_nmiss, void* stream_) {
+    if (!e || !packed || !out_sum || !out_nmiss) return fail(PYRHE_EINVAL, "NULL argument");
+    if (!e->rhs_set) return fail(PYRHE_ESTATE, "pyrhe_engine_set_rhs has not been called (keep mask unknown)");
+    if (n_rows <= 0) return PYRHE_OK;
+    HIPCHK(hipSetDevice(e->device));
+    block_stats_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(packed, e->pitch, n_rows, e->keepmask, out_sum, out_nmiss);
+    HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
+extern "C" int pyrhe_decode_rows(const uint8_t* packed, int64_t n_rows, int64_t pitch, float* out, void* stream_) {
+    if (!packed || !out) return fail(PYRHE_EINVAL, "NULL argument");
+    if (n_rows <= 0) return PYRHE_OK;
+    const int64_t threads = n_rows * pitch;
+    decode_rows_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream_>>>(packed, n_rows, pitch, out);
+    HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
+extern "C" int pyrhe_synth_genotypes(uint8_t* packed, int64_t n_rows, int64_t pitch, int64_t n_samples,
+                                     uint64_t seed, int64_t row0, void* stream_) {
+    if (!packed) return fail(PYRHE_EINVAL, "NULL argument");
+    if (pitch <= 0 || pitch % 4) return fail(PYRHE_EINVAL, "pitch must be a positive multiple of 4");
+    if (n_samples < 0 || n_samples > 4 * pitch) return fail(PYRHE_EINVAL, "n_samples outside 0..4*pitch");
+    if (n_rows <= 0) return PYRHE_OK;
+    const int64_t threads = n_rows * (pitch / 4);
+    if ((threads + 255) / 256 > 0x7fffffffll) return fail(PYRHE_EINVAL, "too many rows for one launch; call per block");
+    synth_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream_>>>(packed, n_rows, pitch, n_samples, seed, row0);
+    HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
+extern "C" int pyrhe_engine_profile(pyrhe_engine_t* e, int enable) {
+    if (!e) return fail(PYRHE_EINVAL, "NULL engine");
+    for (auto& ev : e->evs) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    e->evs.clear();
+    e->profile = enable != 0;
+    return PYRHE_OK;
+}
+
+extern "C" int pyrhe_engine_profile_read(pyrhe_engine_t* e, double* ms_gemm1, double* ms_mid, double* ms_gemm2,
+                                         int64_t* launches) {
+    if (!e) return fail(PYRHE_EINVAL, "NULL engine");
+    double t[3] = {0, 0, 0};
+    int64_t n = 0;
+    for (auto& ev : e->evs) {
+        HIPCHK(hipEventSynchronize(ev.b));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
+        t[ev.kind] += ms;
+        if (ev.kind == 0) ++n;
+    }
+    if (ms_gemm1) *ms_gemm1 = t[0];
+    if (ms_mid) *ms_mid = t[1];
+    if (ms_gemm2) *ms_gemm2 = t[2];
+    if (launches) *launches = n;
+    return PYRHE_OK;
+}

@@ -1,0 +1,236 @@
+"""ctypes binding of the C ABI in ``include/pyrhe_sketch.h`` + a thin torch-tensor wrapper.
+
+PyTorch is plumbing here (device memory, streams); every byte of the sketch is computed by the
+HIP kernels in ``csrc/sketch_engine.hip``.  There is NO CPU fallback: if the shared library is
+missing or no GPU is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from .build import library_path
+
+PREC_F16 = 0
+PREC_F16X2 = 1
+PRECISIONS = {"f16": PREC_F16, "f16x2": PREC_F16X2}
+COL_SKETCH = 1
+COL_NORM = 2
+ROW_ALIGN = 256           # pitch granularity (bytes)
+
+_lib = None
+
+# name -> (restype, argtypes): exactly the symbols include/pyrhe_sketch.h declares
+_vp, _i32, _i64, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
+SYMBOLS = {
+    "pyrhe_last_error": (C.c_char_p, []),
+    "pyrhe_abi_version": (_i32, []),
+    "pyrhe_engine_create": (_i32, [_i32, _i64, _i64, _i64, _i32, _i64, C.POINTER(_vp)]),
+    "pyrhe_engine_destroy": (_i32, [_vp]),
+    "pyrhe_engine_set_rhs": (_i32, [_vp, _vp, C.POINTER(C.c_int32), _i32, _vp, _vp]),
+    "pyrhe_engine_sketch_block": (_i32, [_vp, _vp, _i64, _vp, C.POINTER(_i64), _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "pyrhe_engine_block_stats": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "pyrhe_decode_rows": (_i32, [_vp, _i64, _i64, _vp, _vp]),
+    "pyrhe_synth_genotypes": (_i32, [_vp, _i64, _i64, _i64, _u64, _i64, _vp]),
+    "pyrhe_engine_info": (_i64, [_vp, _i32]),
+    "pyrhe_engine_profile": (_i32, [_vp, _i32]),
+    "pyrhe_engine_profile_read": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
+}
+
+
+def load_library():
+    """dlopen ``libpyrhe_sketch.so`` (built in-tree by ``pyrhe_amd.build``) and bind every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the sketch engine has no CPU fallback)")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class SketchError(RuntimeError):
+    pass
+
+
+def _check(code: int, what: str):
+    if code != 0:
+        msg = load_library().pyrhe_last_error().decode(errors="replace")
+        raise SketchError(f"{what} failed (code {code}): {msg}")
+
+
+def pitch_for(n_samples_orig: int) -> int:
+    """Row pitch in bytes: ceil(N/4) rounded up to 256."""
+    rb = (n_samples_orig + 3) // 4
+    return (rb + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_gpu(device) -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("pyrhe_amd: no ROCm GPU visible -- the sketch engine has no CPU fallback")
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(f"pyrhe_amd: device must be a ROCm GPU, got {device}")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def upload_packed(packed_rows: np.ndarray, device) -> torch.Tensor:
+    """Host ``[m, ceil(N/4)]`` uint8 rows -> device ``[m, pitch]`` (zero padded)."""
+    device = _require_gpu(device)
+    m, rb = packed_rows.shape
+    pitch = (rb + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
+    out = torch.zeros((m, pitch), dtype=torch.uint8, device=device)
+    out[:, :rb] = torch.from_numpy(np.ascontiguousarray(packed_rows)).to(device)
+    return out
+
+
+def synth_genotypes(n_rows: int, n_samples: int, seed: int, row0: int, device, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Device-side synthetic cohort rows (see ``pyrhe_synth_genotypes``)."""
+    device = _require_gpu(device)
+    lib = load_library()
+    pitch = pitch_for(n_samples)
+    if out is None:
+        out = torch.empty((n_rows, pitch), dtype=torch.uint8, device=device)
+    assert out.shape == (n_rows, pitch) and out.is_contiguous()
+    step = max(1, (1 << 30) // pitch)          # keep each launch's grid well inside 2^31 blocks
+    with torch.cuda.device(device):
+        for r in range(0, n_rows, step):
+            n = min(step, n_rows - r)
+            _check(lib.pyrhe_synth_genotypes(C.c_void_p(out[r].data_ptr()), n, pitch, n_samples, seed & (2**64 - 1), row0 + r,
+                                             _stream_ptr(device)), "pyrhe_synth_genotypes")
+    return out
+
+
+def decode_rows(packed: torch.Tensor) -> torch.Tensor:
+    """Dense float32 ``[m, 4*pitch]`` decode of packed rows (NaN = missing call)."""
+    lib = load_library()
+    m, pitch = packed.shape
+    out = torch.empty((m, 4 * pitch), dtype=torch.float32, device=packed.device)
+    with torch.cuda.device(packed.device):
+        _check(lib.pyrhe_decode_rows(_ptr(packed), m, pitch, _ptr(out), _stream_ptr(packed.device)), "pyrhe_decode_rows")
+    return out
+
+
+class SketchEngine:
+    """One engine per GPU.  Mirrors what ``Base._compute_XXz/_XXUz/_yXXy`` + ``standardize_geno`` +
+    ``read_geno`` do for a block (reference ``pyrhe/src/base/base.py:291-296,338-356,403-417``)."""
+
+    def __init__(self, n_samples_orig: int, n_keep: int, max_entries: int, precision: str = "f16x2",
+                 device="cuda", sub_snps: int = 0):
+        self.device = _require_gpu(device)
+        self.lib = load_library()
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {list(PRECISIONS)}")
+        self.precision = precision
+        self.n_samples_orig = int(n_samples_orig)
+        self.n_keep = int(n_keep)
+        self.pitch = pitch_for(n_samples_orig)
+        self.n_pad = 4 * self.pitch
+        self.max_entries = int(max_entries)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.pyrhe_engine_create(self.device.index, self.n_keep, self.pitch, self.max_entries,
+                                                PRECISIONS[precision], int(sub_snps), C.byref(h)), "pyrhe_engine_create")
+        self._h = h
+        self.n_sketch = 0
+        self.n_norm = 0
+        self._keep = None
+        self._rhs = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.pyrhe_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def sub_snps(self) -> int:
+        return int(self.lib.pyrhe_engine_info(self._h, 1))
+
+    def keep_vector(self, missing_indv: Sequence[int] = ()) -> torch.Tensor:
+        keep = torch.zeros(self.n_pad, dtype=torch.float32, device=self.device)
+        keep[: self.n_samples_orig] = 1.0
+        if len(missing_indv):
+            keep[torch.as_tensor(list(missing_indv), device=self.device, dtype=torch.long)] = 0.0
+        return keep
+
+    def set_rhs(self, sketch_cols: Optional[torch.Tensor], norm_cols: Optional[torch.Tensor], keep: torch.Tensor):
+        """sketch_cols ``[n_sketch, n_pad]`` / norm_cols ``[n_norm, n_pad]`` float32 on the device, zero at
+        dropped and padding samples."""
+        parts = [t for t in (sketch_cols, norm_cols) if t is not None and t.shape[0] > 0]
+        R = torch.cat(parts, dim=0).to(torch.float32).contiguous()
+        assert R.shape[1] == self.n_pad and R.device == self.device
+        ns = 0 if sketch_cols is None else sketch_cols.shape[0]
+        nn = 0 if norm_cols is None else norm_cols.shape[0]
+        roles = (C.c_int32 * (ns + nn))(*([COL_SKETCH] * ns + [COL_NORM] * nn))
+        keep = keep.to(torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            _check(self.lib.pyrhe_engine_set_rhs(self._h, _ptr(R), roles, ns + nn, _ptr(keep), _stream_ptr(self.device)),
+                   "pyrhe_engine_set_rhs")
+        self.n_sketch, self.n_norm = ns, nn
+        self._rhs, self._keep = R, keep      # keep alive until the async prep has run
+
+    def sketch_block(self, packed: torch.Tensor, entries: torch.Tensor, offsets: Sequence[int], *,
+                     fill: Optional[torch.Tensor] = None, out_sketch: Optional[torch.Tensor] = None,
+                     out_norm: Optional[torch.Tensor] = None, accumulate: bool = False, want_colsum: bool = False):
+        """Enqueue the sketch of one block; returns ``(out_sketch [nbin, n_sketch, n_pad], out_norm [nbin, n_norm], colsum|None)``."""
+        nbin = len(offsets) - 1
+        assert packed.dtype == torch.uint8 and packed.is_contiguous() and packed.shape[1] == self.pitch
+        assert entries.dtype == torch.int32 and entries.is_contiguous()
+        if out_sketch is None:
+            out_sketch = torch.empty((nbin, self.n_sketch, self.n_pad), dtype=torch.float32, device=self.device)
+            assert not accumulate
+        if out_norm is None:
+            out_norm = torch.empty((nbin, max(self.n_norm, 1)), dtype=torch.float64, device=self.device)
+            assert not accumulate
+        colsum = torch.empty(int(offsets[-1]), dtype=torch.int32, device=self.device) if want_colsum else None
+        offs = (C.c_int64 * (nbin + 1))(*[int(o) for o in offsets])
+        with torch.cuda.device(self.device):
+            _check(self.lib.pyrhe_engine_sketch_block(self._h, _ptr(packed), packed.shape[0], _ptr(entries), offs, nbin,
+                                                      _ptr(fill), _ptr(out_sketch), _ptr(out_norm), _ptr(colsum),
+                                                      1 if accumulate else 0, _stream_ptr(self.device)),
+                   "pyrhe_engine_sketch_block")
+        return out_sketch, out_norm, colsum
+
+    def block_stats(self, packed: torch.Tensor):
+        m = packed.shape[0]
+        s = torch.empty(m, dtype=torch.int32, device=self.device)
+        nm = torch.empty(m, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.pyrhe_engine_block_stats(self._h, _ptr(packed), m, _ptr(s), _ptr(nm), _stream_ptr(self.device)),
+                   "pyrhe_engine_block_stats")
+        return s, nm
+
+    def profile(self, enable: bool):
+        _check(self.lib.pyrhe_engine_profile(self._h, 1 if enable else 0), "pyrhe_engine_profile")
+
+    def profile_read(self):
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        _check(self.lib.pyrhe_engine_profile_read(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)), "pyrhe_engine_profile_read")
+        return {"gemm1_ms": a.value, "mid_ms": b.value, "gemm2_ms": c.value, "launches": n.value}

@@ -1,0 +1,146 @@
+"""GPU parity of the HIP sketch engine (through the C ABI) against the oracle and the goldens.
+
+Tolerances (written here, as the task requires):
+  * decode, genotype sums, block indexing: bit-exact.
+  * per-block sketches X(X^T z), ||X^T y||^2 vs the reference's float32 GEMV results:
+      f16x2 mode: 5e-6 of the block's max |value|   (fp32 accumulation-order noise only)
+      f16   mode: 2e-3 of the block's max |value|   (one fp16 rounding of Z and of W = D V)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import plink, synth
+from oracle import rhe_oracle as O
+from tests.helpers import load_golden, oracle_problem
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f16x2": 5e-6, "f16": 2e-3}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda", 0)
+
+
+def test_decode_bit_exact(dev):
+    from pyrhe_amd import engine
+    rng = np.random.default_rng(0)
+    n = 1003
+    rows = rng.integers(0, 256, size=(37, plink.row_bytes(n)), dtype=np.uint8)
+    d = engine.decode_rows(engine.upload_packed(rows, dev)).cpu().numpy()[:, :n]
+    ref = plink.decode_count_a2(rows, n).T
+    assert np.array_equal(np.isnan(d), np.isnan(ref))
+    assert np.array_equal(np.nan_to_num(d, nan=-1), np.nan_to_num(ref, nan=-1))
+
+
+def test_synth_matches_cpu_twin(dev):
+    from pyrhe_amd import engine
+    n, m = 1000, 9
+    packed = engine.synth_genotypes(m, n, seed=20251212, row0=5, device=dev).cpu().numpy()
+    codes = plink.decode_codes(packed, n)
+    g = np.array([0, -1, 1, 2], np.int8)[codes]
+    assert np.array_equal(g, synth.synth_rows(20251212, 5, m, n))
+    assert not packed[:, plink.row_bytes(n):].any()          # padding bytes are zero
+
+
+def _engine_block_sketches(p, c, dev, precision, fill_by_block=None):
+    """Run the engine block by block; returns XXz [ne, jn, k, N], yXXy [ne, jn], colsums list."""
+    from pyrhe_amd import engine
+    N0 = c.n_indv
+    keep_idx = np.setdiff1d(np.arange(N0), np.array(p.missing_indv, dtype=np.int64))
+    step = p.n_snp // p.n_jack
+    eng = engine.SketchEngine(N0, p.n_indv, max_entries=step + p.n_snp % p.n_jack, precision=precision, device=dev)
+    keep = eng.keep_vector(p.missing_indv)
+    Zp = torch.zeros((p.k, eng.n_pad), dtype=torch.float32, device=dev)
+    Zp[:, torch.as_tensor(keep_idx, device=dev)] = torch.from_numpy(p.Z.T.astype(np.float32)).to(dev)
+    yp = torch.zeros((1, eng.n_pad), dtype=torch.float32, device=dev)
+    yp[0, torch.as_tensor(keep_idx, device=dev)] = torch.from_numpy(p.pheno[:, 0].astype(np.float32)).to(dev)
+    eng.set_rhs(Zp, yp, keep)
+    packed = engine.upload_packed(c.packed, dev)
+    XXz = np.zeros((p.nbin, p.n_jack, p.k, p.n_indv))
+    yXXy = np.zeros((p.nbin, p.n_jack))
+    colsums = []
+    for j in range(p.n_jack):
+        s, e = O.block_range(j, p.n_snp, p.n_jack)
+        ann = p.annot[s:e]
+        ent = [np.nonzero(ann[:, b])[0].astype(np.int32) for b in range(p.nbin)]
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in ent])])
+        entries = torch.from_numpy(np.concatenate(ent).astype(np.int32)).to(dev)
+        fill = None
+        if fill_by_block is not None:
+            fill = torch.from_numpy(fill_by_block[j].astype(np.float32)).to(dev)
+        sk, nm, cs = eng.sketch_block(packed[s:e], entries, offs, fill=fill, want_colsum=True)
+        torch.cuda.synchronize()
+        XXz[:, j] = sk.cpu().numpy()[:, :, keep_idx]
+        yXXy[:, j] = nm.cpu().numpy()[:, 0]
+        colsums.append((cs.cpu().numpy(), ent, s))
+        # dropped / padding samples are written as exact zeros
+        dropped = np.setdiff1d(np.arange(eng.n_pad), keep_idx)
+        assert not sk.cpu().numpy()[:, :, dropped].any()
+    eng.close()
+    return XXz, yXXy, colsums
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "f16"])
+@pytest.mark.parametrize("name", ["rhe_1bin_nocov", "rhe_3bin_nocov_rem", "rhe_1bin_n1024"])
+def test_block_sketch_vs_reference_golden(dev, name, precision):
+    z = load_golden(name)
+    p, c = oracle_problem(z)
+    XXz, yXXy, colsums = _engine_block_sketches(p, c, dev, precision)
+    ref = z["ref_t0_XXz_blocks"].astype(np.float64)          # [ne, jn, k, N] float32 values of the reference
+    refy = z["ref_t0_yXXy_blocks"]
+    tol = TOL[precision]
+    for j in range(p.n_jack):
+        for b in range(p.nbin):
+            scale = np.abs(ref[b, j]).max()
+            if scale == 0:
+                assert not XXz[b, j].any()
+                continue
+            assert np.abs(XXz[b, j] - ref[b, j]).max() <= tol * scale, (j, b)
+            assert abs(yXXy[b, j] - refy[b, j]) <= 2 * tol * abs(refy[b, j]), (j, b)
+    # exact integer genotype sums per entry
+    for cs, ent, s in colsums:
+        exp = np.concatenate([c.geno[s + e_].astype(np.int64).sum(axis=1) for e_ in ent])
+        assert np.array_equal(cs.astype(np.int64), exp)
+
+
+@pytest.mark.parametrize("name", ["rhe_1bin_missing", "rhe_1bin_missing_mean"])
+def test_block_sketch_with_missing_calls(dev, name):
+    """Missing genotype calls + dropped individuals; fill values replayed from NumPy's stream (base.py:265-289)."""
+    z = load_golden(name)
+    p, c = oracle_problem(z)
+    fills = []
+    for j in range(p.n_jack):
+        s, e = O.block_range(j, p.n_snp, p.n_jack)
+        X = O.read_geno(p.packed, p.n_indv_orig, s, e, p.missing_indv)
+        miss = np.isnan(X)
+        np.random.seed(p.seed)                               # non-streaming reseeds per block (base.py:510)
+        Xi = O.impute_geno(X.copy(), p.impute)
+        f = np.zeros(e - s)
+        for m in range(e - s):
+            if miss[:, m].any():
+                f[m] = Xi[miss[:, m], m][0]
+        fills.append(f)
+    XXz, yXXy, _ = _engine_block_sketches(p, c, dev, "f16x2", fill_by_block=fills)
+    ref = z["ref_t0_XXz_blocks"].astype(np.float64)
+    for j in range(p.n_jack):
+        scale = np.abs(ref[0, j]).max()
+        assert np.abs(XXz[0, j] - ref[0, j]).max() <= TOL["f16x2"] * scale, j
+        assert abs(yXXy[0, j] - z["ref_t0_yXXy_blocks"][0, j]) <= 1e-5 * abs(z["ref_t0_yXXy_blocks"][0, j])
+
+
+def test_block_stats_exact(dev):
+    from pyrhe_amd import engine
+    z = load_golden("rhe_1bin_missing")
+    p, c = oracle_problem(z)
+    eng = engine.SketchEngine(c.n_indv, p.n_indv, max_entries=64, precision="f16", device=dev)
+    keep = eng.keep_vector(p.missing_indv)
+    eng.set_rhs(torch.zeros((1, eng.n_pad), device=dev), None, keep)
+    s, nm = eng.block_stats(engine.upload_packed(c.packed, dev))
+    g = np.delete(c.geno.astype(np.int64), p.missing_indv, axis=1)
+    assert np.array_equal(s.cpu().numpy(), np.where(g < 0, 0, g).sum(axis=1))
+    assert np.array_equal(nm.cpu().numpy(), (g < 0).sum(axis=1))
+    eng.close()
