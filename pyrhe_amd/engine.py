@@ -101,7 +101,7 @@ def upload_packed(packed_rows: np.ndarray, device) -> torch.Tensor:
     m, rb = packed_rows.shape
     pitch = (rb + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
     out = torch.zeros((m, pitch), dtype=torch.uint8, device=device)
-    out[:, :rb] = torch.from_numpy(np.ascontiguousarray(packed_rows)).to(device)
+    out[:, :rb] = torch.from_numpy(np.array(packed_rows, dtype=np.uint8, order="C")).to(device)
     return out
 
 

@@ -1,0 +1,149 @@
+"""Host-side estimator: consumes the tiny ``(T, q)`` systems the GPU assembles and reproduces the
+reference's solve / jackknife / heritability arithmetic (``pyrhe/src/base/base.py:298-312,630-825``,
+``pyrhe/src/models/genie/genie.py:146-219``).  O(ne^3) per jackknife sample -- not on the hot path."""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg
+
+
+def solve_normal_equations(T: np.ndarray, q: np.ndarray, method: str = "QR") -> np.ndarray:
+    """``T sigma = q`` by full QR + back-substitution (default, base.py:306-312) or lstsq (base.py:298-303)."""
+    if method == "QR":
+        Qm, Rm = scipy.linalg.qr(T)
+        return np.ravel(scipy.linalg.solve_triangular(Rm, np.dot(Qm.T, q)))
+    if method == "lstsq":
+        return np.ravel(np.linalg.lstsq(T, q, rcond=None)[0])
+    raise ValueError("Unsupported method for solving linear equation")
+
+
+def jackknife_se(ests: np.ndarray, n_jack: int) -> list:
+    """Delete-one-block jackknife SE per column: sqrt((jn-1)/jn * sum_j (theta_j - mean)^2)  (base.py:680-703)."""
+    ests = np.asarray(ests)
+    out = []
+    for col in range(ests.shape[1]):
+        vals = ests[:, col]
+        centre = np.mean(vals)
+        ss = 0
+        for v in vals:
+            ss += (v - centre) ** 2
+        out.append(np.sqrt((n_jack - 1) * ss / n_jack))
+    return out
+
+
+def _stack(jack: np.ndarray, total: np.ndarray) -> np.ndarray:
+    return np.vstack([jack, total[np.newaxis, :]])
+
+
+def h2_nonoverlapping(sigma_jack: np.ndarray, sigma_total: np.ndarray, n_est: int):
+    """h2_e = sigma_e / (sum_g sigma + sigma_err); last column = SNP heritability (base.py:705-742)."""
+    rows = []
+    for s in _stack(sigma_jack, sigma_total):
+        g = 0
+        for e in range(n_est):
+            g += s[e]
+        denom = g + s[-1]
+        rows.append([v / denom for v in s[:-1]] + [g / denom])
+    rows = np.array(rows)
+    return rows[:-1], rows[-1]
+
+
+def h2_overlapping(sigma_jack: np.ndarray, sigma_total: np.ndarray, n_est: int, annot: np.ndarray,
+                   M: np.ndarray, n_snp: int, n_jack: int):
+    """Overlapping-annotation definition (base.py:744-785): every SNP of bin e contributes
+    sum_{bins b containing it} sigma_b / M[j][b].  Row j uses the SNPs outside block j computed with the
+    reference's own index arithmetic (base.py:382-393), which for the total row j = jn masks
+    [jn*step, jn*step + step + M%jn) -- i.e. the trailing M%jn SNPs -- and nothing when M%jn == 0."""
+    step, rem = n_snp // n_jack, n_snp % n_jack
+    rows = []
+    for j, s in enumerate(_stack(sigma_jack, sigma_total)):
+        g = 0
+        for e in range(n_est):
+            g += s[e]
+        denom = g + s[-1]
+        chunk = step if j < n_jack - 1 else step + rem
+        mask = np.ones(n_snp, dtype=bool)
+        mask[j * step: j * step + chunk] = False
+        sub = annot[mask]
+        per_bin = [s[b] / M[j][b] if M[j][b] != 0 else 0 for b in range(n_est)]
+        row = []
+        for e in range(n_est):
+            acc = 0
+            for snp in np.where(sub[:, e] == 1)[0]:
+                inner = 0
+                for b in np.where(sub[snp, :] == 1)[0].tolist():
+                    inner += per_bin[b]
+                acc += inner
+            row.append(acc / denom)
+        row.append(g / denom)
+        rows.append(row)
+    rows = np.array(rows)
+    return rows[:-1], rows[-1]
+
+
+def enrichment(h2_jack: np.ndarray, h2_total: np.ndarray, M: np.ndarray, n_est: int):
+    """(h2_e / h2_SNP) / (M_e / sum M)  per jackknife row (base.py:788-825)."""
+    rows = []
+    for j, h in enumerate(_stack(h2_jack, h2_total)):
+        Mt = sum(M[j])
+        rows.append([(h[e] / h[-1]) / (M[j][e] / Mt) if (Mt != 0 and M[j][e] != 0) else 0 for e in range(n_est)])
+    rows = np.array(rows)
+    return rows[:-1], rows[-1]
+
+
+# ----------------------------------------------------------------------------- GENIE shaping
+def genie_h2(sig_adj_jack: np.ndarray, sig_adj_total: np.ndarray, n_bin: int, n_gxe: int, n_nxe: int = 0):
+    """GENIE heritabilities from trace-adjusted variance components (genie.py:146-189):
+    per-bin g, per-bin gxe, (nxe), total, total_g, [total_gxe]."""
+    ne = n_bin + n_gxe + n_nxe
+    rows = []
+    for s in _stack(sig_adj_jack, sig_adj_total):
+        tv = 0
+        for e in range(ne):
+            tv += s[e]
+        denom = tv + s[-1]
+        row, g_tot, x_tot, n_tot = [], 0, 0, 0
+        for i in range(n_bin):
+            v = s[i] / denom
+            row.append(v)
+            g_tot += v
+        for i in range(n_gxe):
+            v = s[n_bin + i] / denom
+            row.append(v)
+            x_tot += v
+        for i in range(n_nxe):
+            v = s[n_bin + n_gxe + i] / denom
+            row.append(v)
+            n_tot += v
+        row.append(g_tot + x_tot + n_tot)
+        row.append(g_tot)
+        if n_gxe:
+            row.append(x_tot)
+        rows.append(row)
+    rows = np.array(rows)
+    return rows[:-1], rows[-1]
+
+
+def genie_enrichment(h2_jack: np.ndarray, h2_total: np.ndarray, M_last: np.ndarray, n_bin: int):
+    """Enrichment over the genetic bins with the whole-data SNP counts (genie.py:191-219)."""
+    rows = []
+    for h in _stack(h2_jack, h2_total):
+        h_sum, m_sum = 0, 0
+        for i in range(n_bin):
+            h_sum += h[i]
+            m_sum += M_last[i]
+        per_snp = h_sum / m_sum
+        rows.append([(h[i] / M_last[i]) / per_snp for i in range(n_bin)])
+    rows = np.array(rows)
+    return rows[:-1], rows[-1]
+
+
+def liability_scale(h2, se, pop_prev: float, samp_prev: float):
+    """Observed-scale -> liability-scale h2 for case/control traits (base.py:857-868)."""
+    from scipy.stats import chi2, norm
+    K, P = pop_prev, samp_prev
+    zv = norm.pdf(norm.ppf(K))
+    factor = K ** 2 * (1 - K) ** 2 / P / (1 - P) / zv ** 2
+    h2_l = h2 * factor
+    var_l = (se * factor) ** 2
+    return h2_l, var_l ** 0.5, chi2.sf(h2_l ** 2 / var_l, 1)

@@ -1,0 +1,236 @@
+"""Model classes with the reference's user surface -- constructor kwargs, ``model(trait, method="QR") -> dict``,
+result-dict keys and log lines -- running on the MI355X sketch engine.
+
+Reference surface being mirrored: ``pyrhe/src/base/base.py:24-193,874-886`` (constructor, ``__call__``),
+``pyrhe/src/models/rhe/rhe.py:28-101`` (``RHE.run`` log grammar + dict), ``pyrhe/src/models/rhe/streaming_rhe.py``.
+
+Semantics per class:
+  * ``RHE``          -- non-streaming semantics: per-block reseeded imputation stream, ``UXXz = U(block XXz)``.
+  * ``StreamingRHE`` -- the reference's one-worker streaming semantics, including quirk Q4
+                        (``UXXz`` accumulated from the running sum) unless ``compat="fixed"``.
+Both keep the per-block sketches in HBM; ``recompute_pass2=True`` re-sketches blocks in pass 2 instead.
+There is no CPU path: a missing GPU or HIP library raises.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import estimate as est
+from . import io as rio
+from .engine import SketchEngine, upload_packed
+from .logger import Logger
+from .streaming import BlockPlan, SketchRunner, shard_ranges
+
+
+class Base:
+    streaming = False
+
+    def __init__(self, model: str = "rhe", geno_file: str = None, annot_file: str = None, pheno_file: str = None,
+                 cov_file: str = None, num_bin: int = 8, num_jack: int = 1, num_random_vec: int = 10,
+                 geno_impute_method: str = "binary", cov_impute_method: str = "ignore",
+                 cov_one_hot_conversion: Optional[bool] = False, categorical_threshhold: int = 100,
+                 device: str = "cuda", cuda_num: Optional[int] = None, num_workers: Optional[int] = None,
+                 multiprocessing: bool = True, seed: Optional[int] = None, get_trace: bool = False,
+                 trace_dir: Optional[str] = None, samp_prev: Optional[float] = None, pop_prev: Optional[float] = None,
+                 log: Optional[Logger] = None, precision: str = "f16x2", compat: str = "reference",
+                 recompute_pass2: bool = False, sub_snps: int = 0):
+        self.model = model
+        self.num_jack = self.num_blocks = int(num_jack)
+        self.num_random_vec = int(num_random_vec)
+        self.geno_impute_methods = geno_impute_method
+        self.log = log if log is not None else Logger(debug_mode=False)
+        self.precision, self.compat, self.recompute_pass2 = precision, compat, recompute_pass2
+        if self.num_jack < 1:
+            raise ValueError("num_jack must be >= 1")
+        # device: one process per GPU; LOCAL_RANK picks the card under torchrun
+        if str(device) == "cpu":
+            raise RuntimeError("pyrhe_amd runs the sketch on an MI355X only (no CPU path); use device='cuda'")
+        if not torch.cuda.is_available():
+            raise RuntimeError("pyrhe_amd: no ROCm GPU visible")
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        idx = cuda_num if (cuda_num is not None and int(cuda_num) > -1) else int(os.environ.get("LOCAL_RANK", 0))
+        self.device = torch.device("cuda", int(idx))
+        torch.cuda.set_device(self.device)
+        self.log._debug(f"Using device {self.device}")
+
+        # seed -> private legacy stream replaying the reference's global one (base.py:72-73)
+        self.seed = int(time.process_time()) if seed is None else int(seed)
+        rs = np.random.RandomState(self.seed)
+
+        self.num_indv_original, fam_df = rio.read_fam(geno_file + ".fam")
+        self.num_snp = rio.count_bim(geno_file + ".bim")
+        self._rng_prefix = 0
+        if annot_file is None:
+            if num_bin is None:
+                raise ValueError("Must specify number of bins if annot file is not provided")
+            annot_file = "generated_annot"
+            with open(annot_file, "w") as f:                      # file_processing.py:102-111, same draws
+                for _ in range(self.num_snp):
+                    row = [0] * num_bin
+                    row[rs.randint(0, num_bin)] = 1
+                    f.write(" ".join(str(v) for v in row) + "\n")
+            self._rng_prefix = self.num_snp
+        self.num_bin, self.annot_matrix, self.len_bin = rio.read_annot(annot_file)
+
+        self.pheno_file = pheno_file
+        self.pheno, missing_indv, self.binary_pheno = rio.read_pheno(pheno_file)
+        self.num_traits = self.pheno.shape[1]
+        self.log._log(f"Number of traits: {self.num_traits}")
+        if cov_file is None:
+            self.use_cov, self.cov_matrix, self.Q = False, None, None
+            self.missing_indv = missing_indv
+        else:
+            self.use_cov = True
+            self.cov_matrix, self.missing_indv = rio.read_cov(cov_file, missing_indvs=missing_indv, impute=cov_impute_method)
+            self.log._log(f"Rank of the covariate matrix: {np.linalg.matrix_rank(self.cov_matrix)}")
+            self.Q = np.linalg.pinv(self.cov_matrix.T @ self.cov_matrix)
+        self.pheno = np.delete(self.pheno, self.missing_indv, axis=0)
+        self.pheno = self.pheno - np.mean(self.pheno, axis=0)
+        self.num_indv = self.num_indv_original - len(self.missing_indv)
+        for i, m in enumerate(self.missing_indv, start=1):
+            self.log._log(f"missing individual {i}: FID:{fam_df.iloc[m, 0]} IID:{fam_df.iloc[m, 1]}")
+        self.log._log(f"Number of individuals after filtering: {self.num_indv}")
+        if self.cov_matrix is not None:
+            self.log._log(f"Number of covariates: {self.cov_matrix.shape[1]}")
+        self.log._log("*****")
+        for i, n in enumerate(self.len_bin):
+            self.log._log(f"Number of features in bin {i} : {n}")
+
+        self.all_zb = rs.randn(self.num_indv, self.num_random_vec)          # base.py:176
+        if self.use_cov:
+            self.all_Uzb = self.cov_matrix @ self.Q @ (self.cov_matrix.T @ self.all_zb)
+        self.get_trace, self.trace_dir = get_trace, trace_dir
+        self.samp_prev, self.pop_prev = samp_prev, pop_prev
+        self.pheno_cp = self.pheno.copy()
+        self.num_env, self.num_gen_env_bin = 0, 0
+        self.env, self.genie_model = None, None
+
+        # ---- genotype rows of this rank's blocks -> HBM (packed, never decoded on the host)
+        self.plan = BlockPlan(self.annot_matrix, self.num_jack)
+        self.local_blocks = shard_ranges(self.num_jack, self.world)[self.rank]
+        j0, j1 = self.local_blocks
+        packed = rio.read_bed_packed(geno_file + ".bed", self.num_indv_original, self.num_snp)
+        r0 = self.plan.range(j0)[0] if j1 > j0 else 0
+        r1 = self.plan.range(j1 - 1)[1] if j1 > j0 else 0
+        self.geno_dev = upload_packed(np.asarray(packed[r0:r1]), self.device)
+        self.engine = SketchEngine(self.num_indv_original, self.num_indv, max_entries=self.plan.max_block,
+                                   precision=precision, device=self.device, sub_snps=sub_snps)
+        self._runner = None
+
+    # ---- plugin hooks of the reference (base.py:453-463)
+    def get_num_estimates(self):
+        return self.num_bin
+
+    def get_M_last_row(self):
+        return self.len_bin
+
+    def _make_runner(self) -> SketchRunner:
+        return SketchRunner(self.engine, self.geno_dev, self.plan, self.local_blocks, n_orig=self.num_indv_original,
+                            missing_indv=self.missing_indv, Z=self.all_zb, cov=self.cov_matrix, env=self.env,
+                            genie_model=self.genie_model, impute=self.geno_impute_methods, seed=self.seed,
+                            streaming=self.streaming, compat=self.compat, recompute_pass2=self.recompute_pass2,
+                            rng_prefix_draws=self._rng_prefix)
+
+    def pre_compute(self):
+        t0 = time.time()
+        if self._runner is None:
+            self._runner = self._make_runner()
+        self.num_estimates = self.get_num_estimates()
+        self.systems = self._runner.run_trait(self.pheno[:, 0])
+        self.M = self.systems.M
+        self.log._debug(f"Precompute total time: {time.time() - t0}")
+
+    def estimate(self, method: str = "lstsq"):
+        rows = [est.solve_normal_equations(self.systems.T[j], self.systems.q[j].reshape(-1, 1), method)
+                for j in range(self.num_jack + 1)]
+        rows = np.array(rows)
+        return rows[:-1, :], rows[-1, :]
+
+    def estimate_error(self, ests):
+        return est.jackknife_se(ests, self.num_jack)
+
+    def __call__(self, trait, method: str = "QR"):
+        self.pheno = self.pheno_cp[:, trait].reshape(-1, 1)
+        self.log._log("*****")
+        self.log._log(f"OUTPUT FOR TRAIT {trait}: ")
+        self.pre_compute()
+        return self.run(method=method)
+
+    def run(self, method):
+        raise NotImplementedError
+
+
+class RHE(Base):
+    """Additive multi-component RHE (``pyrhe/src/models/rhe/rhe.py``)."""
+
+    def run(self, method):
+        log = self.log._log
+        sigma_jack, sigma_total = self.estimate(method=method)
+        sig_errs = self.estimate_error(sigma_jack)
+        ne = self.num_estimates
+        log("Variance components: ")
+        for i, v in enumerate(sigma_total):
+            if i == len(sigma_total) - 1:
+                log(f"Sigma^2_e : {v}  SE : {sig_errs[i]}")
+            else:
+                log(f"Sigma^2_g[{i}] : {v}  SE : {sig_errs[i]}")
+        h2_jack, h2_total = est.h2_nonoverlapping(sigma_jack, sigma_total, ne)
+        h2_errs = self.estimate_error(h2_jack)
+        log("*****")
+        log("Heritabilities:")
+        for i, v in enumerate(h2_total):
+            if i == len(h2_total) - 1:
+                log(f"Total h2 : {v} SE: {h2_errs[i]}")
+            else:
+                log(f"h2_g[{i}] : {v} : {h2_errs[i]}")
+        log("*****")
+        log("Enrichments: ")
+        enr_jack, enr_total = est.enrichment(h2_jack, h2_total, self.M, ne)
+        enr_errs = self.estimate_error(enr_jack)
+        for i, v in enumerate(enr_total):
+            log(f"Enrichment g[{i}] : {v} SE : {enr_errs[i]}")
+        log("*****\n*****\nHeritabilities and enrichments computed based on overlapping setting")
+        h2o_jack, h2o_total = est.h2_overlapping(sigma_jack, sigma_total, ne, self.annot_matrix, self.M,
+                                                 self.num_snp, self.num_jack)
+        h2o_errs = self.estimate_error(h2o_jack)
+        log("Heritabilities:")
+        for i, v in enumerate(h2o_total):
+            if i == len(h2_total) - 1:
+                log(f"Total h2 : {v} SE: {h2o_errs[i]}")
+            else:
+                log(f"h2_g[{i}] : {v} : {h2o_errs[i]}")
+        log("Enrichments (overlapping def):")
+        enro_jack, enro_total = est.enrichment(h2o_jack, h2o_total, self.M, ne)
+        enro_errs = self.estimate_error(enro_jack)
+        for i, v in enumerate(enro_total):
+            log(f"Enrichment g[{i}] : {v} SE : {enro_errs[i]}")
+        if self.binary_pheno:
+            # the reference calls a method that does not exist here (rhe.py:84,87 vs base.py:857);
+            # this build computes the liability transform it intended when prevalences are given.
+            if self.samp_prev is not None and self.pop_prev is not None:
+                log("*****")
+                log("Liability Scale h2 for binary phenotype:")
+                for i, v in enumerate(h2_total):
+                    out = est.liability_scale(v, h2_errs[i], float(self.pop_prev), float(self.samp_prev))
+                    name = "Total Liability-scale h2" if i == len(h2_total) - 1 else f"Liability-scale h2_g[{i}]"
+                    log(f"{name} : {out[0]}, SE: {out[1]}, p-value: {out[2]}")
+        self.sigma_est_jackknife = sigma_jack
+        return {
+            "sigma_ests_total": sigma_total, "sig_errs": sig_errs,
+            "h2_total": h2_total, "h2_errs": h2_errs,
+            "enrichment_total": enr_total, "enrichment_errs": enr_errs,
+            "h2_total_overlap": h2o_total, "h2_errs_overlap": h2o_errs,
+            "enrichment_total_overlap": enro_total, "enrichment_errs_overlap": enro_errs,
+        }
+
+
+class StreamingRHE(RHE):
+    """``pyrhe/src/models/rhe/streaming_rhe.py`` semantics (one-worker streaming; quirk Q4 unless compat='fixed')."""
+    streaming = True

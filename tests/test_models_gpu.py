@@ -1,0 +1,88 @@
+"""End-to-end parity on the GPU: model classes (file parsing -> HIP sketch -> estimator -> dict/log) against the
+result dicts and log text the REFERENCE produced for the same input files (tests/golden).
+
+Tolerance: 1e-5 relative on every reported number (sigma^2, h2, enrichment and their jackknife SEs), the bound
+BASELINE.json's north_star states, in the parity-safe precision mode f16x2."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures
+from tests.helpers import RESULT_KEYS_RHE, load_golden
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def _run_model(z, tmp_path, cls_name, **extra):
+    from pyrhe_amd import models
+    from pyrhe_amd.logger import Logger
+    c = fixtures.cohort_from_npz(z)
+    paths = fixtures.write_cohort_files(c, str(tmp_path))
+    log = Logger(suppress=True, debug_mode=False)
+    kw = dict(geno_file=paths["geno"], annot_file=paths["annot"], pheno_file=paths["pheno"], cov_file=paths.get("cov"),
+              num_jack=int(z["param_num_jack"]), num_random_vec=int(z["param_num_random_vec"]), seed=int(z["param_seed"]),
+              device="cuda", log=log)
+    if "param_geno_impute_method" in z:
+        kw["geno_impute_method"] = str(z["param_geno_impute_method"])
+    kw.update(extra)
+    m = getattr(models, cls_name)(**kw)
+    return m, log
+
+
+def _assert_dict(res, z, t, keys, rtol=RTOL):
+    for k in keys:
+        ref = z[f"ref_t{t}_res_{k}"]
+        got = np.asarray(res[k], float)
+        # 1e-10 absolute floor: single-bin enrichments are exactly 1 with "SEs" of pure rounding noise (1e-14)
+        assert np.all(np.abs(got - ref) <= rtol * np.abs(ref) + 1e-10), (k, got, ref)
+
+
+@pytest.mark.parametrize("name", ["rhe_1bin_nocov", "rhe_3bin_nocov_rem", "rhe_3bin_cov", "rhe_1bin_missing",
+                                  "rhe_1bin_missing_mean", "rhe_1bin_n1024", "rhe_2bin_jn1", "rhe_1bin_2traits"])
+def test_rhe_matches_reference(name, tmp_path):
+    z = load_golden(name)
+    m, log = _run_model(z, tmp_path, "RHE")
+    assert np.array_equal(m.all_zb, z["ref_all_zb"])
+    for t in range(m.num_traits):
+        n0 = len(log.msgs)
+        res = m(trait=t)
+        assert np.array_equal(m.M, z[f"ref_t{t}_M"])
+        assert np.allclose(m.systems.T, z[f"ref_t{t}_T"], rtol=2e-6, atol=0)
+        _assert_dict(res, z, t, RESULT_KEYS_RHE)
+        # log grammar: same lines, numbers within tolerance
+        ref_lines = str(z[f"ref_t{t}_log"]).splitlines()
+        got_lines = "".join(log.msgs[n0:]).splitlines()
+        assert [re.sub(r"-?\d+\.\d+(e-?\d+)?|nan", "#", l) for l in got_lines] == \
+               [re.sub(r"-?\d+\.\d+(e-?\d+)?|nan", "#", l) for l in ref_lines]
+
+
+def test_streaming_rhe_bug_compatible_and_fixed(tmp_path):
+    z = load_golden("srhe_3bin_cov")
+    m, _ = _run_model(z, tmp_path, "StreamingRHE")
+    res = m(trait=0)
+    _assert_dict(res, z, 0, RESULT_KEYS_RHE)
+    assert np.allclose(m.sigma_est_jackknife, z["ref_t0_sigma_jack"], rtol=RTOL)
+    zf = load_golden("rhe_3bin_cov")                       # same cohort, non-streaming = "fixed" semantics
+    m2, _ = _run_model(zf, tmp_path, "StreamingRHE", compat="fixed")
+    _assert_dict(m2(trait=0), zf, 0, RESULT_KEYS_RHE)
+
+
+def test_recompute_pass2_equals_stored_blocks(tmp_path):
+    z = load_golden("rhe_3bin_nocov_rem")
+    a, _ = _run_model(z, tmp_path, "StreamingRHE")
+    b, _ = _run_model(z, tmp_path, "StreamingRHE", recompute_pass2=True)
+    ra, rb = a(trait=0), b(trait=0)
+    assert np.allclose(ra["sigma_ests_total"], rb["sigma_ests_total"], rtol=1e-12)
+    assert np.allclose(ra["sig_errs"], rb["sig_errs"], rtol=1e-9)
+
+
+def test_f16_mode_close(tmp_path):
+    """Single-rounding mode: documented looser bound on the tiny fixtures (error ~ 2^-12 / sqrt(N k))."""
+    z = load_golden("rhe_1bin_n1024")
+    m, _ = _run_model(z, tmp_path, "RHE", precision="f16")
+    res = m(trait=0)
+    _assert_dict(res, z, 0, ["sigma_ests_total", "h2_total"], rtol=5e-4)
