@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- SNPs/sec through the streaming trace sketch on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE streaming sketch pass over the whole synthetic cohort: every jackknife block goes through
+decode -> per-SNP statistics -> X^T R -> X (X^T R) for k probe vectors + the phenotype norm, the per-block
+sketches are accumulated and the per-bin accumulators are all-reduced over the GPUs (RCCL over xGMI).
+Workload = BASELINE.json configs[2] ("Synthetic N=500k M=1M single-bin StreamingRHE, k=10 jn=100"), the
+configuration the metric is quoted on; genotypes are generated on the device (resident in HBM before the timed
+region) by the counter-based generator that oracle/synth.py reproduces on the CPU.  With N GPUs the SAME cohort
+is sharded by jackknife block (strong scaling).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+SYNTH_SEED = 20251212
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-indv", type=int, default=500_000)
+    ap.add_argument("--n-snp", type=int, default=1_000_000)
+    ap.add_argument("--jn", type=int, default=100)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--precision", default=os.environ.get("PYRHE_PRECISION", "f16"), choices=["f16", "f16x2"])
+    ap.add_argument("--sub-snps", type=int, default=int(os.environ.get("PYRHE_SUB_SNPS", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-snps", type=int, default=0, help="SNPs in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--verify", action="store_true", help="also run pass 2 + solve and print sigma^2")
+    return ap.parse_args()
+
+
+def cpu_baseline(n_indv: int, k: int, n_snps: int) -> dict:
+    """The oracle's reference-order pass-1 body (decode -> flip -> per-SNP impute loop -> standardize -> k float32
+    GEMV pairs + yXXy, float64 accumulate; oracle/rhe_oracle.py restating base_streaming.py:85-104) on a bounded
+    sample of the same synthetic cohort, on this box's host cores."""
+    from oracle import plink, synth
+    from oracle import rhe_oracle as O
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    g = synth.synth_rows(SYNTH_SEED, 0, n_snps, n_indv)
+    packed = plink.encode_bed_rows(g)
+    rng = np.random.default_rng(1)
+    y = rng.normal(size=(n_indv, 1)); y -= y.mean()
+    p = O.Problem(packed=packed, n_indv_orig=n_indv, annot=np.ones((n_snps, 1), np.int64), pheno=y, n_jack=1, k=k, seed=0)
+    p.Z = O.make_probe_vectors(0, n_indv, k)
+    t0 = time.perf_counter()
+    O.sketch_block(p, 0, reseed=False)
+    dt = time.perf_counter() - t0
+    return {"value": n_snps / dt, "unit": "SNPs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"pass-1 body of the reference-order oracle on {n_snps} SNPs x N={n_indv}, k={k}, one block, "
+                      f"torch CPU float32 GEMV pairs ({dt:.1f} s)"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from pyrhe_amd import engine as eng_mod
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner, shard_ranges
+    from pyrhe_amd import estimate as est
+
+    N, M, jn, k = args.n_indv, args.n_snp, args.jn, args.k
+    plan = BlockPlan(np.ones((M, 1), np.int8), jn)
+    j0, j1 = shard_ranges(jn, world)[rank]
+    r0 = plan.range(j0)[0] if j1 > j0 else 0
+    r1 = plan.range(j1 - 1)[1] if j1 > j0 else 0
+    t_gen = time.perf_counter()
+    geno = eng_mod.synth_genotypes(r1 - r0, N, SYNTH_SEED, r0, dev)          # resident in HBM before timing
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    engine = eng_mod.SketchEngine(N, N, max_entries=plan.max_block, precision=args.precision, device=dev,
+                                  sub_snps=args.sub_snps)
+    np.random.seed(0)
+    Z = np.random.randn(N, k)                                               # NumPy legacy stream, seed 0
+    y = np.random.default_rng(1).normal(size=N); y -= y.mean()
+    runner = SketchRunner(engine, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, seed=0, streaming=True)
+    runner.begin_trait(y, check_missing=False)      # the generator emits no missing calls (contract of synth_kernel)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.pass1()
+    barrier()
+    engine.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.pass1()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = engine.profile_read()
+    engine.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = M * args.steps / dt
+
+    row_bytes = (N + 3) // 4
+    local_snps = (r1 - r0) * args.steps
+    launches = max(prof["launches"], 1)
+    g1, g2 = prof["gemm1_ms"], prof["gemm2_ms"]
+    dom = "gemm2_kernel" if g2 >= g1 else "gemm1_kernel"
+    dom_ms = max(g1, g2)
+    bytes_per_launch = local_snps * row_bytes / launches                    # algorithmic bytes: ceil(N/4) per SNP
+    achieved = bytes_per_launch / (dom_ms / launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(dom_ms / launches, 4),
+                "gemm1_ms_per_step": round(g1 / args.steps, 3), "gemm2_ms_per_step": round(g2 / args.steps, 3),
+                "mid_ms_per_step": round(prof["mid_ms"] / args.steps, 3),
+                "pass_frac": round(value * row_bytes / 1e9 / HBM_PEAK_GBS, 4)}
+
+    out = {"metric": "SNPs/sec through streaming trace sketch (N=500k, k=10, jn=100)", "value": value, "unit": "SNPs/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f16" if args.precision == "f16" else "f16x2", "data": "synthetic",
+           "config": {"workload": f"synthetic N={N} M={M} single-bin StreamingRHE sketch pass, k={k} jn={jn}",
+                      "precision": args.precision, "sub_snps": engine.sub_snps, "parallelism": f"blocks/{world}gpu",
+                      "gen_seconds": round(t_gen, 2)},
+           "roofline": roofline}
+
+    if args.verify:
+        sysm = runner.pass2()
+        sig = [est.solve_normal_equations(sysm.T[j], sysm.q[j].reshape(-1, 1)) for j in range(jn + 1)]
+        out["config"]["sigma_total"] = [float(v) for v in sig[-1]]
+        out["config"]["sigma_se"] = [float(v) for v in est.jackknife_se(np.array(sig[:-1]), jn)]
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n_s = args.cpu_baseline_snps or int(min(20000, max(50, 400 * 500_000 / max(N, 1))))
+        try:
+            out["cpu_baseline"] = cpu_baseline(N, k, n_s)
+        except Exception as ex:                                             # the baseline must never sink the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "SNPs/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

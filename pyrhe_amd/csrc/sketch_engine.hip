@@ -598,6 +598,16 @@ struct pyrhe_engine {
     bool profile = false;
     struct Ev { int kind; hipEvent_t a, b; };
     std::vector<Ev> evs;
+    std::vector<hipEvent_t> pool;   // events are created once and reused across profiled passes
+    size_t pool_used = 0;
+    hipEvent_t take_event() {
+        if (pool_used == pool.size()) {
+            hipEvent_t ev;
+            (void)hipEventCreate(&ev);
+            pool.push_back(ev);
+        }
+        return pool[pool_used++];
+    }
     size_t total_bytes = 0;
 };
 
@@ -669,7 +679,7 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
 extern "C" int pyrhe_engine_destroy(pyrhe_engine_t* e) {
     if (!e) return PYRHE_OK;
     hipSetDevice(e->device);
-    for (auto& ev : e->evs) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    for (auto& ev : e->pool) (void)hipEventDestroy(ev);
     hipFree(e->rfrag); hipFree(e->rscale); hipFree(e->csum); hipFree(e->colmax);
     hipFree(e->keepmask); hipFree(e->keep); hipFree(e->ws);
     delete e;
@@ -744,14 +754,14 @@ struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
     ProfScope(pyrhe_engine* e_, hipStream_t s_, int kind_) : e(e_), s(s_), kind(kind_) {
         if (e->profile) {
-            hipEventCreate(&a);
-            hipEventCreate(&b);
-            hipEventRecord(a, s);
+            a = e->take_event();
+            b = e->take_event();
+            (void)hipEventRecord(a, s);
         }
     }
     ~ProfScope() {
         if (e->profile) {
-            hipEventRecord(b, s);
+            (void)hipEventRecord(b, s);
             e->evs.push_back({kind, a, b});
         }
     }
@@ -914,8 +924,8 @@ extern "C" int pyrhe_synth_genotypes(uint8_t* packed, int64_t n_rows, int64_t pi
 
 extern "C" int pyrhe_engine_profile(pyrhe_engine_t* e, int enable) {
     if (!e) return fail(PYRHE_EINVAL, "NULL engine");
-    for (auto& ev : e->evs) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     e->evs.clear();
+    e->pool_used = 0;
     e->profile = enable != 0;
     return PYRHE_OK;
 }

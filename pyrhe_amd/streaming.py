@@ -275,18 +275,26 @@ class SketchRunner:
 
     def run_trait(self, y: np.ndarray, check_missing: bool = True) -> Systems:
         """Pass 1 + pass 2 for one centred phenotype ``y [N]``; returns the jn+1 normal-equation systems (every rank)."""
-        plan, k, ne, nb = self.plan, self.k, self.n_est, self.plan.n_bin
-        jn = plan.n_jack
-        jl = self.j1 - self.j0
+        self.begin_trait(y, check_missing)
+        self.pass1()
+        return self.pass2()
+
+    def begin_trait(self, y: np.ndarray, check_missing: bool = True):
+        """Install the right-hand columns and allocate the per-block sketch store."""
+        nb, jl = self.plan.n_bin, self.j1 - self.j0
         self._check_missing = check_missing
         self._install_rhs(y)
         dev = self.device
-        blocks_sk = torch.empty((jl, nb, self.n_sketch, self.n_pad), dtype=torch.float32, device=dev)
-        blocks_nm = torch.zeros((max(jl, 1), nb, self.n_norm), dtype=torch.float64, device=dev)
-        self.sketch_local_blocks(blocks_sk, blocks_nm, pass_index=0)
-        self.blocks_sk, self.blocks_nm = blocks_sk, blocks_nm
+        self.blocks_sk = torch.empty((jl, nb, self.n_sketch, self.n_pad), dtype=torch.float32, device=dev)
+        self.blocks_nm = torch.zeros((max(jl, 1), nb, self.n_norm), dtype=torch.float64, device=dev)
 
-        # ---- aggregate (base_streaming.py:21-58 / base.py:465-500): float64 sums in block order
+    def pass1(self):
+        """One streaming sketch pass over the local blocks (base_streaming.py:85-104) + aggregate
+        (base_streaming.py:21-58 / base.py:465-500: float64 sums in block order) + the cross-GPU all-reduce."""
+        plan, k, nb = self.plan, self.k, self.plan.n_bin
+        jn, jl, dev = plan.n_jack, self.j1 - self.j0, self.device
+        blocks_sk, blocks_nm = self.blocks_sk, self.blocks_nm
+        self.sketch_local_blocks(blocks_sk, blocks_nm, pass_index=0)
         tot_sk = torch.zeros((nb, self.n_sketch, self.n_pad), dtype=torch.float64, device=dev)
         tot_nm = torch.zeros((nb, self.n_norm), dtype=torch.float64, device=dev)
         use_cov = self.cov is not None
@@ -294,7 +302,7 @@ class SketchRunner:
         wsum = torch.zeros_like(D_tot) if (use_cov and self.world > 1) else None
         q4 = use_cov and self.streaming and self.compat == "reference"
         for jl_i in range(jl):
-            blk = blocks_sk[jl_i].to(torch.float64)
+            blk = blocks_sk[jl_i]
             tot_sk += blk
             tot_nm += blocks_nm[jl_i]
             if use_cov:
@@ -302,7 +310,7 @@ class SketchRunner:
                     # quirk Q4 (streaming_rhe.py:18-21): U applied to the RUNNING sum of XXz, float32
                     D_tot += self._apply_U(tot_sk[:, :k], f32=True)
                 elif q4:
-                    wsum += blk[:, :k] * float(jn - (self.j0 + jl_i))
+                    wsum += blk[:, :k].to(torch.float64) * float(jn - (self.j0 + jl_i))
                 else:
                     D_tot += self._apply_U(blk[:, :k], f32=True)
         if self.world > 1:
@@ -316,22 +324,26 @@ class SketchRunner:
                     self._allreduce(D_tot)
         self.tot_sk, self.tot_nm, self.D_tot = tot_sk, tot_nm, D_tot
 
-        # ---- M (rhe.py:16): SNPs of every estimate outside block j
+    def pass2(self) -> Systems:
+        """Leave-one-out normal equations where each block lives (base_streaming.py:110-144), gathered to every rank."""
+        plan, k, ne = self.plan, self.k, self.n_est
+        jn = plan.n_jack
+        use_cov = self.cov is not None
+        tot_sk, tot_nm, D_tot = self.tot_sk, self.tot_nm, self.D_tot
+        # M (rhe.py:16): SNPs of every estimate outside block j
         M = np.zeros((jn + 1, ne), np.int64)
         last = np.concatenate([plan.len_bin, plan.len_bin]) if self.n_gxe else plan.len_bin
         M[jn] = last
         for j in range(jn):
             c = plan.block_counts(j)
             M[j] = last - (np.concatenate([c, c]) if self.n_gxe else c)
-
-        # ---- pass 2: leave-one-out systems where the block lives
         yy = float(self.y_res @ self.y_res)
         local = []
         for jl_i, j in enumerate(range(self.j0, self.j1)):
             if self.recompute_pass2:
                 sk, nm, _ = self._resketch(j)
             else:
-                sk, nm = blocks_sk[jl_i], blocks_nm[jl_i]
+                sk, nm = self.blocks_sk[jl_i], self.blocks_nm[jl_i]
             slot = jn if (jn == 1 and j == 0) else j          # base.py:654-655
             if slot == jn:
                 T, q = self._system(tot_sk, tot_nm, D_tot, M[jn], yy)
