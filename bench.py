@@ -44,11 +44,12 @@ def parse_args():
     ap.add_argument("--n-snp", type=int, default=1_000_000)
     ap.add_argument("--jn", type=int, default=100)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--precision", default=os.environ.get("PYRHE_PRECISION", "f16"), choices=["f16", "f16x2"])
+    ap.add_argument("--precision", default=os.environ.get("PYRHE_PRECISION", "f16"), choices=["f16", "f16x2", "f16e"])
     ap.add_argument("--sub-snps", type=int, default=int(os.environ.get("PYRHE_SUB_SNPS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-snps", type=int, default=0, help="SNPs in the CPU baseline sample (0 = auto)")
     ap.add_argument("--verify", action="store_true", help="also run pass 2 + solve and print sigma^2")
+    ap.add_argument("--h2", type=float, default=0.5, help="heritable share of the --verify phenotype")
     return ap.parse_args()
 
 
@@ -104,6 +105,17 @@ def main():
     np.random.seed(0)
     Z = np.random.randn(N, k)                                               # NumPy legacy stream, seed 0
     y = np.random.default_rng(1).normal(size=N); y -= y.mean()
+    if args.verify and args.h2 > 0:
+        # heritable phenotype for the parity check between precision modes: y = a * (K r) + b * noise, K r = X X^T r / M
+        r = np.random.default_rng(7).normal(size=(N, 1))
+        rr = SketchRunner(engine, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=r, seed=0, streaming=True)
+        rr.begin_trait(y, check_missing=False)
+        rr.pass1()
+        g = rr.tot_sk[0, 0, :N].cpu().numpy()
+        del rr
+        g = (g - g.mean()) / g.std()
+        y = np.sqrt(args.h2) * g + np.sqrt(1 - args.h2) * y / y.std()
+        y -= y.mean()
     runner = SketchRunner(engine, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, seed=0, streaming=True)
     runner.begin_trait(y, check_missing=False)      # the generator emits no missing calls (contract of synth_kernel)
 
@@ -148,7 +160,7 @@ def main():
     out = {"metric": "SNPs/sec through streaming trace sketch (N=500k, k=10, jn=100)", "value": value, "unit": "SNPs/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "f16" if args.precision == "f16" else "f16x2", "data": "synthetic",
+           "dtype": "f16x2" if args.precision == "f16x2" else "f16", "data": "synthetic",
            "config": {"workload": f"synthetic N={N} M={M} single-bin StreamingRHE sketch pass, k={k} jn={jn}",
                       "precision": args.precision, "sub_snps": engine.sub_snps, "parallelism": f"blocks/{world}gpu",
                       "gen_seconds": round(t_gen, 2)},

@@ -43,6 +43,8 @@ extern "C" {
 /* precision modes: how the float32 operands R and W = D V are fed to the fp16 matrix cores */
 #define PYRHE_PREC_F16 0    /* one fp16 rounding (11 significant bits), 1 MFMA pass            */
 #define PYRHE_PREC_F16X2 1  /* hi + lo fp16 split (~22 significant bits), 2 MFMA passes        */
+#define PYRHE_PREC_F16_EXACT 2 /* one fp16 rounding, genotypes unpacked to normal fp16 numbers (3 VALU ops per
+                                  register pair instead of the 1-op subnormal unpack of PYRHE_PREC_F16)        */
 
 /* column roles for pyrhe_engine_set_rhs */
 #define PYRHE_COL_SKETCH 1  /* gets both contractions: out[:, col] = X (X^T r)   (a7/a9 in SURVEY 8a) */

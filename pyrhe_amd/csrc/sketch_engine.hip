@@ -79,12 +79,20 @@ __device__ __forceinline__ uint32_t apply_fill(uint32_t v, uint32_t miss, int fi
     return fill == 0 ? v - miss : (fill == 2 ? v + miss : v);
 }
 
-// Two genotypes -> one register of two exact fp16 values, for crumb position t = 0..3 of each 16-bit
-// half of x:  (x & (3 << 2t)) | 0x6400 is the fp16 number 1024 + c * 4^t (c lands in the mantissa);
-// one packed fma  h * 4^-t - 1024 * 4^-t  returns c exactly.
-template <int T>
+// Two genotypes -> one register of two fp16 values.  Two variants:
+//  EXACT = false (precision f16): ONE v_and_b32.  For crumb position t = 0..3 of each 16-bit half of x,
+//     (x & (3 << 2t)) read as fp16 is the SUBNORMAL number c * 4^t * 2^-24 (exponent field 0).  The matrix
+//     cores multiply fp16 subnormals (tools/microbench.hip E1: exact against small integers), so the constant
+//     4^t * 2^-24 is folded into the other operand (GEMM 1: R image pre-divided by 4^t) or into the epilogue
+//     (GEMM 2: one accumulator per crumb position), never paid per genotype.  Measured caveat (E1b): with a
+//     subnormal operand the MFMA keeps ~19 significant bits of each product -- invisible next to the single
+//     fp16 rounding of this mode, too coarse for the hi+lo mode.
+//  EXACT = true (precision f16x2): (x & mask) | 0x6400 is the NORMAL fp16 number 1024 + c * 4^t; one packed fma
+//     h * 4^-t - 1024 * 4^-t returns c exactly (3 VALU ops per register instead of 1).
+template <int T, bool EXACT>
 __device__ __forceinline__ uint32_t unpack(uint32_t x) {
     constexpr uint32_t mask = 0x00030003u << (2 * T);
+    if (!EXACT) return x & mask;
     constexpr float sc = T == 0 ? 1.0f : (T == 1 ? 0.25f : (T == 2 ? 0.0625f : 0.015625f));
     const uint32_t m = (x & mask) | 0x64006400u;
     const half2v hx = __builtin_bit_cast(half2v, m);
@@ -93,13 +101,14 @@ __device__ __forceinline__ uint32_t unpack(uint32_t x) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(hx, s, b));
 }
 // 8 genotypes (crumbs 0..3 of both 16-bit halves of x) -> MFMA operand fragment.
-// k-slot j of the fragment = crumb (j>>1) of half (j&1).
+// k-slot j of the fragment = crumb (j>>1) of half (j&1) (times 4^(j>>1) * 2^-24 when !EXACT).
+template <bool EXACT>
 __device__ __forceinline__ half8 unpack4(uint32_t x) {
     Frag f;
-    f.u[0] = unpack<0>(x);
-    f.u[1] = unpack<1>(x);
-    f.u[2] = unpack<2>(x);
-    f.u[3] = unpack<3>(x);
+    f.u[0] = unpack<0, EXACT>(x);
+    f.u[1] = unpack<1, EXACT>(x);
+    f.u[2] = unpack<2, EXACT>(x);
+    f.u[3] = unpack<3, EXACT>(x);
     return f.h;
 }
 
@@ -130,7 +139,7 @@ __device__ __forceinline__ int64_t g1_sample(int64_t chunk, int d, int h, int q,
 }
 
 // Rfrag layout: [chunk][d 4][h 2][part][tile][lane 64][8 halves]; lane = q*16 + c
-template <int PARTS>
+template <int PARTS, bool EXACT>
 __global__ void prep_rfrag_kernel(const float* __restrict__ R, const float* __restrict__ keep,
                                   int64_t n_pad, int n_user_cols, int ntl,
                                   const uint32_t* __restrict__ colmax_bits, float* __restrict__ scale,
@@ -163,11 +172,14 @@ __global__ void prep_rfrag_kernel(const float* __restrict__ R, const float* __re
             float x = 0.0f;
             if (c < n_user_cols) x = R[(int64_t)c * n_pad + i] * s;
             else if (is_ones) x = keep[i];
+            // the subnormal unpack (!EXACT): compensate the 4^(j>>1) carried by the genotype of k-slot j
+            const float slot = EXACT ? 1.0f : (jj == 0 ? 1.0f : (jj == 1 ? 0.25f : (jj == 2 ? 0.0625f : 0.015625f)));
+            x *= slot;
             _Float16 hi = (_Float16)x;
             _Float16 val = hi;
             if (PARTS == 2 && part == 1) val = (_Float16)(x - (float)hi);
             v2[b] = val;
-            acc += (double)(float)val;
+            acc += (double)(float)val / (double)slot;
         }
         half2v hv = {v2[0], v2[1]};
         f.u[jj] = __builtin_bit_cast(uint32_t, hv);
@@ -191,23 +203,30 @@ __global__ void prep_keepmask_kernel(const float* __restrict__ keep, int64_t n_p
 }
 
 // ------------------------------------------------------------------------------------------------
-// GEMM 1:  P[e][c] = sum_i G[i, row(e)] * Rh[i][c]
-// workgroup = 4 waves, each wave owns 4 tiles of 16 entries (64 SNP rows) over one sample range.
+// GEMM 1:  P[e][c] = 2^-24 * sum_i G[i, row(e)] * Rh[i][c]
+// workgroup = 4 waves in lockstep over one sample range; each wave owns 4 tiles of 16 entries (64 SNP
+// rows), so a 256-sample step reads 16 rows x 64 B per load instruction and reuses every R fragment 4x
+// from registers.  The R operand image of the step (8 fragments x NTL x PARTS KiB) is staged once per
+// workgroup through a double-buffered LDS ring; the packed genotype words of step c+1 are in flight
+// while step c is decoded and multiplied (register prefetch, one barrier per step).
 // ------------------------------------------------------------------------------------------------
-template <int NTL, int PARTS, bool MISSING>
+template <int NTL, int PARTS, bool EXACT, bool MISSING>
 __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                     const int32_t* __restrict__ rows, int n_entries,
                                                     const float* __restrict__ fill,
                                                     const half8* __restrict__ rfrag, int n_chunks,
                                                     int chunks_per_split, float* __restrict__ P,
                                                     int use_atomic) {
+    constexpr int FR = 8 * PARTS * NTL;          // fragments (1 KiB each) per 256-sample step
+    constexpr int LD = FR / 4;                   // 16-byte pieces each thread stages per step
+    __shared__ half8 rbuf[2][FR * 64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int ebase = (blockIdx.x * 4 + wave) * 64;
-    if (ebase >= n_entries) return;
     const int c0 = blockIdx.y * chunks_per_split;
     const int c1 = min(c0 + chunks_per_split, n_chunks);
+    if (c0 >= c1) return;
 
     const uint8_t* rowp[4];
     int fillv[4];
@@ -225,11 +244,29 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
 #pragma unroll
         for (int n = 0; n < NTL; ++n) acc[t][n] = (float4v){0.f, 0.f, 0.f, 0.f};
 
-    for (int c = c0; c < c1; ++c) {
-        uint4 g[4];
+    uint4 g[4], gn[4];
+    half8 rs[LD];
+    // prologue: step c0
 #pragma unroll
-        for (int t = 0; t < 4; ++t) g[t] = *reinterpret_cast<const uint4*>(rowp[t] + (int64_t)c * 64);
-        const half8* rf = rfrag + (int64_t)c * (8 * PARTS * NTL * 64) + lane;
+    for (int t = 0; t < 4; ++t) g[t] = *reinterpret_cast<const uint4*>(rowp[t] + (int64_t)c0 * 64);
+    {
+        const half8* src = rfrag + (int64_t)c0 * (FR * 64) + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < LD; ++i) rbuf[0][i * 256 + threadIdx.x] = src[i * 256];
+    }
+    __syncthreads();
+
+    for (int c = c0; c < c1; ++c) {
+        const int cur = (c - c0) & 1;
+        const bool more = c + 1 < c1;
+        if (more) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) gn[t] = *reinterpret_cast<const uint4*>(rowp[t] + (int64_t)(c + 1) * 64);
+            const half8* src = rfrag + (int64_t)(c + 1) * (FR * 64) + threadIdx.x;
+#pragma unroll
+            for (int i = 0; i < LD; ++i) rs[i] = src[i * 256];
+        }
+        const half8* rf = &rbuf[cur][lane];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             uint32_t v[4];
@@ -248,7 +285,7 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
                     for (int n = 0; n < NTL; ++n) b[p][n] = rf[(((d * 2 + h) * PARTS + p) * NTL + n) * 64];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const half8 a = unpack4(h ? (v[t] >> 8) : v[t]);
+                    const half8 a = unpack4<EXACT>(h ? (v[t] >> 8) : v[t]);
 #pragma unroll
                     for (int p = 0; p < PARTS; ++p)
 #pragma unroll
@@ -257,6 +294,13 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
                 }
             }
         }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < LD; ++i) rbuf[cur ^ 1][i * 256 + threadIdx.x] = rs[i];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) g[t] = gn[t];
+        }
+        __syncthreads();
     }
     // D: lane holds rows 4q + reg (entry), col r
 #pragma unroll
@@ -277,7 +321,7 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // mid 1: per entry statistics, V = X^T R, norm accumulation, W = D V (float32) + column maxima
 // ------------------------------------------------------------------------------------------------
-__global__ void mid1_kernel(const float* __restrict__ P, int n_entries, int ncol_p, int n_sketch, int n_norm,
+__global__ void mid1_kernel(const float* __restrict__ P, float pscale, int n_entries, int ncol_p, int n_sketch, int n_norm,
                             const float* __restrict__ scale, const double* __restrict__ csum, float n_keep,
                             float* __restrict__ mu_out, float* __restrict__ Wtmp,
                             uint32_t* __restrict__ wmax_bits, double* __restrict__ norm_acc,
@@ -287,7 +331,7 @@ __global__ void mid1_kernel(const float* __restrict__ P, int n_entries, int ncol
     float mu = 0.f, d = 0.f;
     const bool live = e < n_entries;
     if (live) {
-        const float sum = P[(int64_t)e * ncol_p + ones];   // exact integer (< 2^24)
+        const float sum = P[(int64_t)e * ncol_p + ones] * pscale;   // exact integer (< 2^24); P carries 1/pscale (2^-24 with the subnormal unpack)
         // float32, the reference's operation order (base.py:292-293): mean; 1/sqrt(mean*(1-0.5*mean))
         mu = sum / n_keep;
         d = 1.0f / sqrtf(mu * (1.0f - 0.5f * mu));
@@ -298,7 +342,7 @@ __global__ void mid1_kernel(const float* __restrict__ P, int n_entries, int ncol
         float v = 0.f;
         if (live) {
             const double inv_s = 1.0 / (double)scale[c];
-            const double pc = (double)P[(int64_t)e * ncol_p + c] * inv_s;
+            const double pc = (double)P[(int64_t)e * ncol_p + c] * (double)pscale * inv_s;
             v = (float)((double)d * (pc - (double)mu * (csum[c] * inv_s)));
         }
         if (c < n_sketch) {
@@ -365,10 +409,13 @@ __global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restr
 
 // ------------------------------------------------------------------------------------------------
 // GEMM 2:  out[c][i] (+)= keep[i] * ( sum_e G[i, row(e)] * Wh[e][c] - corr[c] ) / s_c
-// workgroup = 4 waves; a wave owns 256 samples (one 64-byte column group of the packed rows) and
-// walks the entry list 32 SNPs at a time: lane (n, q) reads dword n of rows 8q..8q+7.
+// workgroup = 4 waves; a wave owns 256*IW samples (IW dwords per lane per SNP row) and walks the entry
+// list 32 SNPs at a time: lane (n, q) reads IW dwords of rows 8q..8q+7 (16 lanes x 4*IW B contiguous
+// per row).  Rows, W fragments and packed words of step kb+1 are in flight while step kb is decoded
+// and multiplied.  MFMA u consumes crumb u of every dword, so the accumulator of MFMA u carries the
+// constant 4^(u&3) * 2^-24 of unpack(), removed once in the epilogue.
 // ------------------------------------------------------------------------------------------------
-template <int NTO, int PARTS, bool MISSING>
+template <int NTO, int PARTS, int IW, bool EXACT, bool MISSING>
 __global__ __launch_bounds__(256) void gemm2_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                     const int32_t* __restrict__ rows32, int n_kb,
                                                     int kb_per_split, const float* __restrict__ fill,
@@ -378,76 +425,129 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const uint8_t* __restrict__ 
                                                     const float* __restrict__ keep, int n_sketch,
                                                     int64_t n_pad, float* __restrict__ out, int mode) {
     // mode: 0 store, 1 read-modify-write, 2 atomicAdd
+    constexpr int NU = 16 * IW;                  // MFMAs (= samples per lane) per step
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     const int64_t grp = (int64_t)blockIdx.x * 4 + wave;
-    if (grp * 256 >= n_pad) return;
+    if (grp * (256 * IW) >= n_pad) return;
     const int kb0 = blockIdx.y * kb_per_split;
     const int kb1 = min(kb0 + kb_per_split, n_kb);
-    const uint8_t* colp = packed + grp * 64 + n * 4;
+    if (kb0 >= kb1) return;
+    const uint8_t* colp = packed + grp * (64 * IW) + n * (4 * IW);
 
-    float4v acc[NTO][16];
+    float4v acc[NTO][NU];
 #pragma unroll
     for (int t = 0; t < NTO; ++t)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc[t][u] = (float4v){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < NU; ++u) acc[t][u] = (float4v){0.f, 0.f, 0.f, 0.f};
 
-    for (int kb = kb0; kb < kb1; ++kb) {
+    auto load_rows = [&](int kb, int (&rr)[8]) {
         const int4* rp = reinterpret_cast<const int4*>(rows32 + (int64_t)kb * 32 + q * 8);
         const int4 r0 = rp[0], r1 = rp[1];
-        const int rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-        uint32_t v[8];
+        rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w;
+        rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
+    };
+    auto load_words = [&](const int (&rr)[8], uint32_t (&w)[8][IW]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(colp + (int64_t)rr[j] * pitch);
-            v[j] = value_code(w);
-            if (MISSING) v[j] = apply_fill(v[j], missing_mask(w), (int)fill[rr[j]]);
+            const uint8_t* a = colp + (int64_t)rr[j] * pitch;
+            if (IW == 1) {
+                w[j][0] = *reinterpret_cast<const uint32_t*>(a);
+            } else {
+                const uint2 t2 = *reinterpret_cast<const uint2*>(a);
+                w[j][0] = t2.x;
+                w[j][IW - 1] = t2.y;
+            }
         }
-        half8 a[PARTS][NTO];
+    };
+    auto load_w = [&](int kb, half8 (&a)[PARTS][NTO]) {
         const half8* wf = wfrag + (int64_t)kb * (PARTS * NTO * 64) + lane;
 #pragma unroll
         for (int p = 0; p < PARTS; ++p)
 #pragma unroll
             for (int t = 0; t < NTO; ++t) a[p][t] = wf[(p * NTO + t) * 64];
-        // x[p]: low halves of rows 2p (lo 16 bits) and 2p+1 (hi 16 bits) = samples 0..7 of the dword;
-        // y[p]: high halves = samples 8..15.
-        uint32_t x[4], y[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            x[p] = __builtin_amdgcn_perm(v[2 * p + 1], v[2 * p], 0x05040100u);
-            y[p] = __builtin_amdgcn_perm(v[2 * p + 1], v[2 * p], 0x07060302u);
+    };
+
+    int rr_cur[8], rr_nxt[8];
+    uint32_t w_cur[8][IW], w_nxt[8][IW];
+    half8 a_cur[PARTS][NTO], a_nxt[PARTS][NTO];
+    load_rows(kb0, rr_cur);
+    load_words(rr_cur, w_cur);
+    load_w(kb0, a_cur);
+    if (kb0 + 1 < kb1) load_rows(kb0 + 1, rr_nxt);
+
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const bool more = kb + 1 < kb1;
+        if (more) {
+            load_words(rr_nxt, w_nxt);
+            load_w(kb + 1, a_nxt);
         }
+        int rr_nn[8];
+        if (kb + 2 < kb1) load_rows(kb + 2, rr_nn);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            Frag f;
+        for (int iw = 0; iw < IW; ++iw) {
+            uint32_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = value_code(w_cur[j][iw]);
+                if (MISSING) v[j] = apply_fill(v[j], missing_mask(w_cur[j][iw]), (int)fill[rr_cur[j]]);
+            }
+            // x[p]: low halves of rows 2p (lo 16 bits) and 2p+1 (hi 16 bits) = samples 0..7 of the dword;
+            // y[p]: high halves = samples 8..15.
+            uint32_t x[4], y[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                uint32_t src = (u & 8) ? y[p] : x[p];
-                if (u & 4) src >>= 8;
-                switch (u & 3) {
-                    case 0: f.u[p] = unpack<0>(src); break;
-                    case 1: f.u[p] = unpack<1>(src); break;
-                    case 2: f.u[p] = unpack<2>(src); break;
-                    default: f.u[p] = unpack<3>(src); break;
+                x[p] = __builtin_amdgcn_perm(v[2 * p + 1], v[2 * p], 0x05040100u);
+                y[p] = __builtin_amdgcn_perm(v[2 * p + 1], v[2 * p], 0x07060302u);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                Frag f;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    uint32_t src = (u & 8) ? y[p] : x[p];
+                    if (u & 4) src >>= 8;
+                    switch (u & 3) {
+                        case 0: f.u[p] = unpack<0, EXACT>(src); break;
+                        case 1: f.u[p] = unpack<1, EXACT>(src); break;
+                        case 2: f.u[p] = unpack<2, EXACT>(src); break;
+                        default: f.u[p] = unpack<3, EXACT>(src); break;
+                    }
                 }
+#pragma unroll
+                for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+                    for (int t = 0; t < NTO; ++t)
+                        acc[t][iw * 16 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[p][t], f.h, acc[t][iw * 16 + u], 0, 0, 0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                rr_cur[j] = rr_nxt[j];
+                rr_nxt[j] = rr_nn[j];
+#pragma unroll
+                for (int iw = 0; iw < IW; ++iw) w_cur[j][iw] = w_nxt[j][iw];
             }
 #pragma unroll
             for (int p = 0; p < PARTS; ++p)
 #pragma unroll
-                for (int t = 0; t < NTO; ++t)
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[p][t], f.h, acc[t][u], 0, 0, 0);
+                for (int t = 0; t < NTO; ++t) a_cur[p][t] = a_nxt[p][t];
         }
     }
-    // D[row = column c = 4q + reg][col = n]; for MFMA u the sample is 256 grp + 16 n + u:
-    // a lane owns 16 consecutive samples per (tile, reg).
-    const int64_t i0 = grp * 256 + n * 16;
-    float kp[16];
+    // D[row = column c = 4q + reg][col = n]; for MFMA (iw, u) the sample is (256 IW) grp + (16 IW) n + 16 iw + u:
+    // a lane owns 16*IW consecutive samples per (tile, reg).
+    const int64_t i0 = grp * (256 * IW) + n * NU;
+    float kp[NU];
 #pragma unroll
-    for (int u4 = 0; u4 < 4; ++u4) {
+    for (int u4 = 0; u4 < NU / 4; ++u4) {
         const float4 k4 = *reinterpret_cast<const float4*>(keep + i0 + 4 * u4);
         kp[4 * u4] = k4.x; kp[4 * u4 + 1] = k4.y; kp[4 * u4 + 2] = k4.z; kp[4 * u4 + 3] = k4.w;
     }
+    // undo the unpack constant: 2^24 * 4^-(u&3)
+    const float usc[4] = {EXACT ? 1.0f : 16777216.0f, EXACT ? 1.0f : 4194304.0f,
+                          EXACT ? 1.0f : 1048576.0f, EXACT ? 1.0f : 262144.0f};
 #pragma unroll
     for (int t = 0; t < NTO; ++t)
 #pragma unroll
@@ -458,12 +558,12 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const uint8_t* __restrict__ 
             const float inv = 1.0f / wscale[c];
             float* dst = out + (int64_t)c * n_pad + i0;
 #pragma unroll
-            for (int u4 = 0; u4 < 4; ++u4) {
+            for (int u4 = 0; u4 < NU / 4; ++u4) {
                 float4 val;
-                val.x = (acc[t][4 * u4 + 0][reg] - cr) * inv * kp[4 * u4 + 0];
-                val.y = (acc[t][4 * u4 + 1][reg] - cr) * inv * kp[4 * u4 + 1];
-                val.z = (acc[t][4 * u4 + 2][reg] - cr) * inv * kp[4 * u4 + 2];
-                val.w = (acc[t][4 * u4 + 3][reg] - cr) * inv * kp[4 * u4 + 3];
+                val.x = (acc[t][4 * u4 + 0][reg] * usc[0] - cr) * inv * kp[4 * u4 + 0];
+                val.y = (acc[t][4 * u4 + 1][reg] * usc[1] - cr) * inv * kp[4 * u4 + 1];
+                val.z = (acc[t][4 * u4 + 2][reg] * usc[2] - cr) * inv * kp[4 * u4 + 2];
+                val.w = (acc[t][4 * u4 + 3][reg] * usc[3] - cr) * inv * kp[4 * u4 + 3];
                 float4* d4 = reinterpret_cast<float4*>(dst + 4 * u4);
                 if (mode == 0) {
                     *d4 = val;
@@ -572,6 +672,7 @@ struct pyrhe_engine {
     int device = 0;
     int64_t n_keep = 0, pitch = 0, n_pad = 0, max_entries = 0, sub_snps = 0;
     int precision = 0, parts = 1;
+    bool exact = false;   // exact (normal-number) genotype unpack instead of the 1-op subnormal unpack
     int n_sketch = 0, n_norm = 0, n_user = 0, ntl = 0, nto = 0;
     bool rhs_set = false;
     // device buffers
@@ -619,7 +720,8 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     if (pitch <= 0 || pitch % 256) return fail(PYRHE_EINVAL, "pitch (%lld) must be a positive multiple of 256", (long long)pitch);
     if (n_keep <= 0 || n_keep > 4 * pitch) return fail(PYRHE_EINVAL, "n_keep (%lld) must be in 1..4*pitch", (long long)n_keep);
     if (n_keep >= (1 << 23)) return fail(PYRHE_EINVAL, "n_keep (%lld) >= 2^23: genotype sums would not be exact in float32", (long long)n_keep);
-    if (precision != PYRHE_PREC_F16 && precision != PYRHE_PREC_F16X2) return fail(PYRHE_EINVAL, "unknown precision %d", precision);
+    if (precision != PYRHE_PREC_F16 && precision != PYRHE_PREC_F16X2 && precision != PYRHE_PREC_F16_EXACT)
+        return fail(PYRHE_EINVAL, "unknown precision %d", precision);
     if (max_entries <= 0) return fail(PYRHE_EINVAL, "max_entries must be positive");
     HIPCHK(hipSetDevice(device));
     auto* e = new pyrhe_engine();
@@ -629,10 +731,12 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     e->n_pad = 4 * pitch;
     e->precision = precision;
     e->parts = precision == PYRHE_PREC_F16X2 ? 2 : 1;
+    e->exact = precision != PYRHE_PREC_F16;
     if (sub_snps <= 0) {
-        // keep one sub-block (<= 96 MiB of packed rows) resident in the 256 MiB Infinity Cache between GEMM 1 and GEMM 2
-        sub_snps = (int64_t)(96ll << 20) / pitch;
-        if (sub_snps < 64) sub_snps = 64;
+        // Whole blocks per kernel pair.  Measured on MI355X (tools/microbench.hip E2): re-reading a sub-block that
+        // was just streamed (Infinity Cache) is at most ~20 % faster than HBM, while short launches lose more than
+        // that to fill/drain -- so sub-blocks only bound the workspace (P, W image: 16384 x 32 floats = 2 MiB).
+        sub_snps = 16384;
     }
     sub_snps = (sub_snps + 31) / 32 * 32;
     if (sub_snps > max_entries) sub_snps = (max_entries + 31) / 32 * 32;
@@ -733,9 +837,11 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
         const int64_t threads = (e->n_pad / 256) * 8 * e->parts * e->ntl * 64;
         const unsigned grid = (unsigned)((threads + 255) / 256);
         if (e->parts == 2)
-            prep_rfrag_kernel<2><<<grid, 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale, e->rfrag, e->csum);
+            prep_rfrag_kernel<2, true><<<grid, 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale, e->rfrag, e->csum);
+        else if (e->exact)
+            prep_rfrag_kernel<1, true><<<grid, 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale, e->rfrag, e->csum);
         else
-            prep_rfrag_kernel<1><<<grid, 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale, e->rfrag, e->csum);
+            prep_rfrag_kernel<1, false><<<grid, 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale, e->rfrag, e->csum);
     }
     {
         const int64_t words = e->n_pad / 16;
@@ -767,24 +873,24 @@ struct ProfScope {
     }
 };
 
-template <int NTL, int PARTS>
+template <int NTL, int PARTS, bool EXACT>
 static void launch_gemm1(pyrhe_engine* e, const uint8_t* packed, const int32_t* rows, int n, const float* fill,
                          int n_chunks, int cps, int splits, hipStream_t stream) {
     dim3 grid((n + 255) / 256, splits);
     if (fill)
-        gemm1_kernel<NTL, PARTS, true><<<grid, 256, 0, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_chunks, cps, e->P, splits > 1);
+        gemm1_kernel<NTL, PARTS, EXACT, true><<<grid, 256, 0, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_chunks, cps, e->P, splits > 1);
     else
-        gemm1_kernel<NTL, PARTS, false><<<grid, 256, 0, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_chunks, cps, e->P, splits > 1);
+        gemm1_kernel<NTL, PARTS, EXACT, false><<<grid, 256, 0, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_chunks, cps, e->P, splits > 1);
 }
 
-template <int NTO, int PARTS>
+template <int NTO, int PARTS, int IW, bool EXACT>
 static void launch_gemm2(pyrhe_engine* e, const uint8_t* packed, int n_kb, int kbps, int splits, const float* fill,
                          float* out, int mode, hipStream_t stream) {
-    dim3 grid((unsigned)(e->n_pad / 1024), splits);
+    dim3 grid((unsigned)((e->n_pad + 1024 * IW - 1) / (1024 * IW)), splits);
     if (fill)
-        gemm2_kernel<NTO, PARTS, true><<<grid, 256, 0, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode);
+        gemm2_kernel<NTO, PARTS, IW, EXACT, true><<<grid, 256, 0, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode);
     else
-        gemm2_kernel<NTO, PARTS, false><<<grid, 256, 0, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode);
+        gemm2_kernel<NTO, PARTS, IW, EXACT, false><<<grid, 256, 0, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode);
 }
 
 __global__ void add_norm_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, int accumulate) {
@@ -842,15 +948,16 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                 const int cps = (n_chunks + splits - 1) / splits;
                 splits = (n_chunks + cps - 1) / cps;
                 ProfScope ps(e, stream, 0);
-                if (e->ntl == 1 && e->parts == 1) launch_gemm1<1, 1>(e, packed, rows, n, fill, n_chunks, cps, splits, stream);
-                else if (e->ntl == 1 && e->parts == 2) launch_gemm1<1, 2>(e, packed, rows, n, fill, n_chunks, cps, splits, stream);
-                else if (e->ntl == 2 && e->parts == 1) launch_gemm1<2, 1>(e, packed, rows, n, fill, n_chunks, cps, splits, stream);
-                else launch_gemm1<2, 2>(e, packed, rows, n, fill, n_chunks, cps, splits, stream);
+#define G1(NTL_, PARTS_, EX_) launch_gemm1<NTL_, PARTS_, EX_>(e, packed, rows, n, fill, n_chunks, cps, splits, stream)
+                if (e->parts == 2) { if (e->ntl == 1) G1(1, 2, true); else G1(2, 2, true); }
+                else if (e->exact) { if (e->ntl == 1) G1(1, 1, true); else G1(2, 1, true); }
+                else { if (e->ntl == 1) G1(1, 1, false); else G1(2, 1, false); }
+#undef G1
             }
             // ---- mid
             {
                 ProfScope ps(e, stream, 1);
-                mid1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
+                mid1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->exact ? 1.0f : 16777216.0f, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
                                                                  (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->normacc,
                                                                  out_colsum ? out_colsum + offsets_host[b] + s0 : nullptr);
                 if (e->n_sketch) {
@@ -863,8 +970,11 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
             }
             // ---- GEMM 2
             if (e->n_sketch) {
-                const int gx = (int)(e->n_pad / 1024);
-                int splits = gx >= 256 ? 1 : (512 + gx - 1) / gx;
+                // 512 samples per wave (8-byte loads, 128 B per row per 16 lanes) when the accumulators fit and the
+                // grid still fills the chip; otherwise 256 samples per wave
+                const int iw = (e->nto == 1 && e->n_pad >= 2048 * 160) ? 2 : 1;
+                const int gx = (int)((e->n_pad + 1024 * iw - 1) / (1024 * iw));
+                int splits = gx >= 192 ? 1 : (512 + gx - 1) / gx;
                 splits = std::max(1, std::min(splits, n_kb));
                 const int kbps = (n_kb + splits - 1) / splits;
                 splits = (n_kb + kbps - 1) / kbps;
@@ -877,10 +987,15 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                     mode = acc_now ? 1 : 0;
                 }
                 ProfScope ps(e, stream, 2);
-                if (e->nto == 1 && e->parts == 1) launch_gemm2<1, 1>(e, packed, n_kb, kbps, splits, fill, outb, mode, stream);
-                else if (e->nto == 1 && e->parts == 2) launch_gemm2<1, 2>(e, packed, n_kb, kbps, splits, fill, outb, mode, stream);
-                else if (e->nto == 2 && e->parts == 1) launch_gemm2<2, 1>(e, packed, n_kb, kbps, splits, fill, outb, mode, stream);
-                else launch_gemm2<2, 2>(e, packed, n_kb, kbps, splits, fill, outb, mode, stream);
+#define G2(NTO_, PARTS_, IW_, EX_) launch_gemm2<NTO_, PARTS_, IW_, EX_>(e, packed, n_kb, kbps, splits, fill, outb, mode, stream)
+                if (e->parts == 2) {
+                    if (iw == 2) G2(1, 2, 2, true); else if (e->nto == 1) G2(1, 2, 1, true); else G2(2, 2, 1, true);
+                } else if (e->exact) {
+                    if (iw == 2) G2(1, 1, 2, true); else if (e->nto == 1) G2(1, 1, 1, true); else G2(2, 1, 1, true);
+                } else {
+                    if (iw == 2) G2(1, 1, 2, false); else if (e->nto == 1) G2(1, 1, 1, false); else G2(2, 1, 1, false);
+                }
+#undef G2
             }
             first = false;
         }

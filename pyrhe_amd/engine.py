@@ -17,7 +17,8 @@ from .build import library_path
 
 PREC_F16 = 0
 PREC_F16X2 = 1
-PRECISIONS = {"f16": PREC_F16, "f16x2": PREC_F16X2}
+PREC_F16_EXACT = 2
+PRECISIONS = {"f16": PREC_F16, "f16x2": PREC_F16X2, "f16e": PREC_F16_EXACT}
 COL_SKETCH = 1
 COL_NORM = 2
 ROW_ALIGN = 256           # pitch granularity (bytes)
