@@ -203,30 +203,32 @@ __global__ void prep_keepmask_kernel(const float* __restrict__ keep, int64_t n_p
 }
 
 // ------------------------------------------------------------------------------------------------
-// GEMM 1:  P[e][c] = 2^-24 * sum_i G[i, row(e)] * Rh[i][c]
+// GEMM 1:  P[e][c] = (2^-24) * sum_i G[i, row(e)] * Rh[i][c]
 // workgroup = 4 waves in lockstep over one sample range; each wave owns 4 tiles of 16 entries (64 SNP
-// rows), so a 256-sample step reads 16 rows x 64 B per load instruction and reuses every R fragment 4x
-// from registers.  The R operand image of the step (8 fragments x NTL x PARTS KiB) is staged once per
-// workgroup through a double-buffered LDS ring; the packed genotype words of step c+1 are in flight
-// while step c is decoded and multiplied (register prefetch, one barrier per step).
+// rows).  One step = 512 samples = one full 128-byte line of every row (two 64-byte halves per lane
+// group), so no line is ever fetched for half its bytes; every R fragment is reused 4x from registers.
+// The R operand image of the step (16 fragments x NTL x PARTS KiB) is staged once per workgroup through
+// a double-buffered LDS ring; the packed genotype words of step s+1 are in flight while step s is
+// decoded and multiplied (register prefetch, one barrier per step).
 // ------------------------------------------------------------------------------------------------
 template <int NTL, int PARTS, bool EXACT, bool MISSING>
 __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                     const int32_t* __restrict__ rows, int n_entries,
                                                     const float* __restrict__ fill,
-                                                    const half8* __restrict__ rfrag, int n_chunks,
-                                                    int chunks_per_split, float* __restrict__ P,
+                                                    const half8* __restrict__ rfrag, int n_steps,
+                                                    int steps_per_split, float* __restrict__ P,
                                                     int use_atomic) {
-    constexpr int FR = 8 * PARTS * NTL;          // fragments (1 KiB each) per 256-sample step
-    constexpr int LD = FR / 4;                   // 16-byte pieces each thread stages per step
-    __shared__ half8 rbuf[2][FR * 64];
+    constexpr int CH = 2;                        // 256-sample chunks per step
+    constexpr int FR = 8 * PARTS * NTL;          // fragments (1 KiB each) per chunk
+    constexpr int LD = CH * FR / 4;              // 16-byte pieces each thread stages per step
+    extern __shared__ __attribute__((aligned(16))) half8 rbuf[];   // [2][CH * FR * 64]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int ebase = (blockIdx.x * 4 + wave) * 64;
-    const int c0 = blockIdx.y * chunks_per_split;
-    const int c1 = min(c0 + chunks_per_split, n_chunks);
-    if (c0 >= c1) return;
+    const int s0 = blockIdx.y * steps_per_split;
+    const int s1 = min(s0 + steps_per_split, n_steps);
+    if (s0 >= s1) return;
 
     const uint8_t* rowp[4];
     int fillv[4];
@@ -244,63 +246,77 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
 #pragma unroll
         for (int n = 0; n < NTL; ++n) acc[t][n] = (float4v){0.f, 0.f, 0.f, 0.f};
 
-    uint4 g[4], gn[4];
+    uint4 g[2][4][CH];
     half8 rs[LD];
-    // prologue: step c0
+    auto issue_g = [&](int s, uint4 (&gg)[4][CH]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) g[t] = *reinterpret_cast<const uint4*>(rowp[t] + (int64_t)c0 * 64);
-    {
-        const half8* src = rfrag + (int64_t)c0 * (FR * 64) + threadIdx.x;
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < LD; ++i) rbuf[0][i * 256 + threadIdx.x] = src[i * 256];
-    }
-    __syncthreads();
-
-    for (int c = c0; c < c1; ++c) {
-        const int cur = (c - c0) & 1;
-        const bool more = c + 1 < c1;
-        if (more) {
+            for (int ch = 0; ch < CH; ++ch)
+                gg[t][ch] = *reinterpret_cast<const uint4*>(rowp[t] + (int64_t)s * (64 * CH) + 64 * ch);
+    };
+    auto issue_r = [&](int s) {
+        const half8* src = rfrag + (int64_t)s * (CH * FR * 64) + threadIdx.x;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) gn[t] = *reinterpret_cast<const uint4*>(rowp[t] + (int64_t)(c + 1) * 64);
-            const half8* src = rfrag + (int64_t)(c + 1) * (FR * 64) + threadIdx.x;
+        for (int i = 0; i < LD; ++i) rs[i] = src[i * 256];
+    };
+    auto stage_r = [&](int buf) {
 #pragma unroll
-            for (int i = 0; i < LD; ++i) rs[i] = src[i * 256];
-        }
-        const half8* rf = &rbuf[cur][lane];
+        for (int i = 0; i < LD; ++i) rbuf[buf * (CH * FR * 64) + i * 256 + threadIdx.x] = rs[i];
+    };
+    auto compute = [&](const uint4 (&gg)[4][CH], int buf) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            uint32_t v[4];
+        for (int ch = 0; ch < CH; ++ch) {
+            const half8* rf = rbuf + buf * (CH * FR * 64) + ch * (FR * 64) + lane;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t w = d == 0 ? g[t].x : (d == 1 ? g[t].y : (d == 2 ? g[t].z : g[t].w));
-                v[t] = value_code(w);
-                if (MISSING) v[t] = apply_fill(v[t], missing_mask(w), fillv[t]);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                half8 b[PARTS][NTL];
-#pragma unroll
-                for (int p = 0; p < PARTS; ++p)
-#pragma unroll
-                    for (int n = 0; n < NTL; ++n) b[p][n] = rf[(((d * 2 + h) * PARTS + p) * NTL + n) * 64];
+            for (int d = 0; d < 4; ++d) {
+                uint32_t v[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const half8 a = unpack4<EXACT>(h ? (v[t] >> 8) : v[t]);
+                    const uint32_t w = d == 0 ? gg[t][ch].x : (d == 1 ? gg[t][ch].y : (d == 2 ? gg[t][ch].z : gg[t][ch].w));
+                    v[t] = value_code(w);
+                    if (MISSING) v[t] = apply_fill(v[t], missing_mask(w), fillv[t]);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    half8 b[PARTS][NTL];
 #pragma unroll
                     for (int p = 0; p < PARTS; ++p)
 #pragma unroll
-                        for (int n = 0; n < NTL; ++n)
-                            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[p][n], acc[t][n], 0, 0, 0);
+                        for (int n = 0; n < NTL; ++n) b[p][n] = rf[(((d * 2 + h) * PARTS + p) * NTL + n) * 64];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const half8 a = unpack4<EXACT>(h ? (v[t] >> 8) : v[t]);
+#pragma unroll
+                        for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+                            for (int n = 0; n < NTL; ++n)
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[p][n], acc[t][n], 0, 0, 0);
+                    }
                 }
             }
         }
-        if (more) {
+    };
+
+    // prologue: step s0
+    issue_g(s0, g[0]);
+    issue_r(s0);
+    stage_r(0);
+    __syncthreads();
+    for (int s = s0; s < s1; s += 2) {
 #pragma unroll
-            for (int i = 0; i < LD; ++i) rbuf[cur ^ 1][i * 256 + threadIdx.x] = rs[i];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) g[t] = gn[t];
+        for (int k = 0; k < 2; ++k) {
+            if (s + k < s1) {
+                const bool more = s + k + 1 < s1;
+                if (more) {
+                    issue_g(s + k + 1, g[k ^ 1]);
+                    issue_r(s + k + 1);
+                }
+                compute(g[k], k);
+                if (more) stage_r(k ^ 1);
+                __syncthreads();
+            }
         }
-        __syncthreads();
     }
     // D: lane holds rows 4q + reg (entry), col r
 #pragma unroll
@@ -411,9 +427,11 @@ __global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restr
 // GEMM 2:  out[c][i] (+)= keep[i] * ( sum_e G[i, row(e)] * Wh[e][c] - corr[c] ) / s_c
 // workgroup = 4 waves; a wave owns 256*IW samples (IW dwords per lane per SNP row) and walks the entry
 // list 32 SNPs at a time: lane (n, q) reads IW dwords of rows 8q..8q+7 (16 lanes x 4*IW B contiguous
-// per row).  Rows, W fragments and packed words of step kb+1 are in flight while step kb is decoded
-// and multiplied.  MFMA u consumes crumb u of every dword, so the accumulator of MFMA u carries the
-// constant 4^(u&3) * 2^-24 of unpack(), removed once in the epilogue.
+// per row).  The packed words and W fragments of the next NS-1 steps are in flight in a register ring
+// while a step is decoded and multiplied (HBM latency x bandwidth needs ~64-128 KiB in flight per CU);
+// the row indices of the workgroup's K range sit in LDS, so no dependent global load ever drains the
+// in-order vector-memory queue.  MFMA u consumes crumb u of every dword: with the subnormal unpack the
+// accumulator of MFMA u carries the constant 4^(u&3) * 2^-24, removed once in the epilogue.
 // ------------------------------------------------------------------------------------------------
 template <int NTO, int PARTS, int IW, bool EXACT, bool MISSING>
 __global__ __launch_bounds__(256) void gemm2_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
@@ -426,14 +444,18 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const uint8_t* __restrict__ 
                                                     int64_t n_pad, float* __restrict__ out, int mode) {
     // mode: 0 store, 1 read-modify-write, 2 atomicAdd
     constexpr int NU = 16 * IW;                  // MFMAs (= samples per lane) per step
+    constexpr int NS = 3;                        // register ring depth
+    extern __shared__ __attribute__((aligned(16))) int32_t s_rows[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     const int64_t grp = (int64_t)blockIdx.x * 4 + wave;
-    if (grp * (256 * IW) >= n_pad) return;
     const int kb0 = blockIdx.y * kb_per_split;
     const int kb1 = min(kb0 + kb_per_split, n_kb);
     if (kb0 >= kb1) return;
+    for (int i = threadIdx.x; i < (kb1 - kb0) * 32; i += 256) s_rows[i] = rows32[(int64_t)kb0 * 32 + i];
+    __syncthreads();
+    if (grp * (256 * IW) >= n_pad) return;
     const uint8_t* colp = packed + grp * (64 * IW) + n * (4 * IW);
 
     float4v acc[NTO][NU];
@@ -442,56 +464,41 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const uint8_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < NU; ++u) acc[t][u] = (float4v){0.f, 0.f, 0.f, 0.f};
 
-    auto load_rows = [&](int kb, int (&rr)[8]) {
-        const int4* rp = reinterpret_cast<const int4*>(rows32 + (int64_t)kb * 32 + q * 8);
+    uint32_t w[NS][8][IW];
+    half8 a[NS][PARTS][NTO];
+    int fl[NS][8];
+
+    auto issue = [&](int kb, uint32_t (&ww)[8][IW], half8 (&aa)[PARTS][NTO], int (&ff)[8]) {
+        const int4* rp = reinterpret_cast<const int4*>(s_rows + (kb - kb0) * 32 + q * 8);
         const int4 r0 = rp[0], r1 = rp[1];
-        rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w;
-        rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
-    };
-    auto load_words = [&](const int (&rr)[8], uint32_t (&w)[8][IW]) {
+        const int rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint8_t* a = colp + (int64_t)rr[j] * pitch;
+            const uint8_t* p = colp + (int64_t)rr[j] * pitch;
             if (IW == 1) {
-                w[j][0] = *reinterpret_cast<const uint32_t*>(a);
+                ww[j][0] = *reinterpret_cast<const uint32_t*>(p);
             } else {
-                const uint2 t2 = *reinterpret_cast<const uint2*>(a);
-                w[j][0] = t2.x;
-                w[j][IW - 1] = t2.y;
+                const uint2 t2 = *reinterpret_cast<const uint2*>(p);
+                ww[j][0] = t2.x;
+                ww[j][IW - 1] = t2.y;
             }
+            if (MISSING) ff[j] = (int)fill[rr[j]];
         }
-    };
-    auto load_w = [&](int kb, half8 (&a)[PARTS][NTO]) {
         const half8* wf = wfrag + (int64_t)kb * (PARTS * NTO * 64) + lane;
 #pragma unroll
         for (int p = 0; p < PARTS; ++p)
 #pragma unroll
-            for (int t = 0; t < NTO; ++t) a[p][t] = wf[(p * NTO + t) * 64];
+            for (int t = 0; t < NTO; ++t) aa[p][t] = wf[(p * NTO + t) * 64];
     };
 
-    int rr_cur[8], rr_nxt[8];
-    uint32_t w_cur[8][IW], w_nxt[8][IW];
-    half8 a_cur[PARTS][NTO], a_nxt[PARTS][NTO];
-    load_rows(kb0, rr_cur);
-    load_words(rr_cur, w_cur);
-    load_w(kb0, a_cur);
-    if (kb0 + 1 < kb1) load_rows(kb0 + 1, rr_nxt);
-
-    for (int kb = kb0; kb < kb1; ++kb) {
-        const bool more = kb + 1 < kb1;
-        if (more) {
-            load_words(rr_nxt, w_nxt);
-            load_w(kb + 1, a_nxt);
-        }
-        int rr_nn[8];
-        if (kb + 2 < kb1) load_rows(kb + 2, rr_nn);
+    auto compute = [&](const uint32_t (&ww)[8][IW], const half8 (&aa)[PARTS][NTO], const int (&ff)[8]) {
 #pragma unroll
         for (int iw = 0; iw < IW; ++iw) {
             uint32_t v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                v[j] = value_code(w_cur[j][iw]);
-                if (MISSING) v[j] = apply_fill(v[j], missing_mask(w_cur[j][iw]), (int)fill[rr_cur[j]]);
+                v[j] = value_code(ww[j][iw]);
+                if (MISSING) v[j] = apply_fill(v[j], missing_mask(ww[j][iw]), ff[j]);
             }
             // x[p]: low halves of rows 2p (lo 16 bits) and 2p+1 (hi 16 bits) = samples 0..7 of the dword;
             // y[p]: high halves = samples 8..15.
@@ -519,21 +526,21 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const uint8_t* __restrict__ 
                 for (int p = 0; p < PARTS; ++p)
 #pragma unroll
                     for (int t = 0; t < NTO; ++t)
-                        acc[t][iw * 16 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[p][t], f.h, acc[t][iw * 16 + u], 0, 0, 0);
+                        acc[t][iw * 16 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aa[p][t], f.h, acc[t][iw * 16 + u], 0, 0, 0);
             }
         }
-        if (more) {
+    };
+
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                rr_cur[j] = rr_nxt[j];
-                rr_nxt[j] = rr_nn[j];
+    for (int s = 0; s < NS; ++s)
+        if (kb0 + s < kb1) issue(kb0 + s, w[s], a[s], fl[s]);
+    for (int kb = kb0; kb < kb1; kb += NS) {
 #pragma unroll
-                for (int iw = 0; iw < IW; ++iw) w_cur[j][iw] = w_nxt[j][iw];
+        for (int s = 0; s < NS; ++s) {
+            if (kb + s < kb1) {
+                compute(w[s], a[s], fl[s]);
+                if (kb + s + NS < kb1) issue(kb + s + NS, w[s], a[s], fl[s]);
             }
-#pragma unroll
-            for (int p = 0; p < PARTS; ++p)
-#pragma unroll
-                for (int t = 0; t < NTO; ++t) a_cur[p][t] = a_nxt[p][t];
         }
     }
     // D[row = column c = 4q + reg][col = n]; for MFMA (iw, u) the sample is (256 IW) grp + (16 IW) n + 16 iw + u:
@@ -875,12 +882,13 @@ struct ProfScope {
 
 template <int NTL, int PARTS, bool EXACT>
 static void launch_gemm1(pyrhe_engine* e, const uint8_t* packed, const int32_t* rows, int n, const float* fill,
-                         int n_chunks, int cps, int splits, hipStream_t stream) {
+                         int n_steps, int sps, int splits, hipStream_t stream) {
     dim3 grid((n + 255) / 256, splits);
+    const size_t lds = (size_t)2 * 2 * 8 * PARTS * NTL * 1024;   // [2 buffers][2 chunks][8 PARTS NTL fragments][1 KiB]
     if (fill)
-        gemm1_kernel<NTL, PARTS, EXACT, true><<<grid, 256, 0, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_chunks, cps, e->P, splits > 1);
+        gemm1_kernel<NTL, PARTS, EXACT, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_steps, sps, e->P, splits > 1);
     else
-        gemm1_kernel<NTL, PARTS, EXACT, false><<<grid, 256, 0, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_chunks, cps, e->P, splits > 1);
+        gemm1_kernel<NTL, PARTS, EXACT, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_steps, sps, e->P, splits > 1);
 }
 
 template <int NTO, int PARTS, int IW, bool EXACT>
@@ -888,9 +896,9 @@ static void launch_gemm2(pyrhe_engine* e, const uint8_t* packed, int n_kb, int k
                          float* out, int mode, hipStream_t stream) {
     dim3 grid((unsigned)((e->n_pad + 1024 * IW - 1) / (1024 * IW)), splits);
     if (fill)
-        gemm2_kernel<NTO, PARTS, IW, EXACT, true><<<grid, 256, 0, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode);
+        gemm2_kernel<NTO, PARTS, IW, EXACT, true><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode);
     else
-        gemm2_kernel<NTO, PARTS, IW, EXACT, false><<<grid, 256, 0, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode);
+        gemm2_kernel<NTO, PARTS, IW, EXACT, false><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode);
 }
 
 __global__ void add_norm_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, int accumulate) {
@@ -943,12 +951,13 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
             // ---- GEMM 1
             {
                 const int gx = (n + 255) / 256;
+                const int n_steps = n_chunks / 2;                 // 512-sample steps (pitch is a multiple of 256 B)
                 int splits = (768 + gx - 1) / gx;
-                splits = std::max(1, std::min(splits, n_chunks / 8 > 0 ? n_chunks / 8 : 1));
-                const int cps = (n_chunks + splits - 1) / splits;
-                splits = (n_chunks + cps - 1) / cps;
+                splits = std::max(1, std::min(splits, n_steps / 4 > 0 ? n_steps / 4 : 1));
+                const int cps = (n_steps + splits - 1) / splits;  // steps per split
+                splits = (n_steps + cps - 1) / cps;
                 ProfScope ps(e, stream, 0);
-#define G1(NTL_, PARTS_, EX_) launch_gemm1<NTL_, PARTS_, EX_>(e, packed, rows, n, fill, n_chunks, cps, splits, stream)
+#define G1(NTL_, PARTS_, EX_) launch_gemm1<NTL_, PARTS_, EX_>(e, packed, rows, n, fill, n_steps, cps, splits, stream)
                 if (e->parts == 2) { if (e->ntl == 1) G1(1, 2, true); else G1(2, 2, true); }
                 else if (e->exact) { if (e->ntl == 1) G1(1, 1, true); else G1(2, 1, true); }
                 else { if (e->ntl == 1) G1(1, 1, false); else G1(2, 1, false); }
@@ -975,6 +984,7 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                 const int iw = (e->nto == 1 && e->n_pad >= 2048 * 160) ? 2 : 1;
                 const int gx = (int)((e->n_pad + 1024 * iw - 1) / (1024 * iw));
                 int splits = gx >= 192 ? 1 : (512 + gx - 1) / gx;
+                splits = std::max(splits, (n_kb + 511) / 512);        // row list of a K range lives in LDS: <= 64 KiB
                 splits = std::max(1, std::min(splits, n_kb));
                 const int kbps = (n_kb + splits - 1) / splits;
                 splits = (n_kb + kbps - 1) / kbps;
