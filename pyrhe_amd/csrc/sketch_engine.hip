@@ -268,6 +268,16 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
             const half8* rf = rbuf + buf * (CH * FR * 64) + ch * (FR * 64) + lane;
+            // all fragments of the chunk are read from LDS back to back (one latency), then consumed
+            half8 b[4][2][PARTS][NTL];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int p = 0; p < PARTS; ++p)
+#pragma unroll
+                        for (int n = 0; n < NTL; ++n) b[d][h][p][n] = rf[(((d * 2 + h) * PARTS + p) * NTL + n) * 64];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 uint32_t v[4];
@@ -279,11 +289,6 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    half8 b[PARTS][NTL];
-#pragma unroll
-                    for (int p = 0; p < PARTS; ++p)
-#pragma unroll
-                        for (int n = 0; n < NTL; ++n) b[p][n] = rf[(((d * 2 + h) * PARTS + p) * NTL + n) * 64];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const half8 a = unpack4<EXACT>(h ? (v[t] >> 8) : v[t]);
@@ -291,14 +296,16 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
                         for (int p = 0; p < PARTS; ++p)
 #pragma unroll
                             for (int n = 0; n < NTL; ++n)
-                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[p][n], acc[t][n], 0, 0, 0);
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[d][h][p][n], acc[t][n], 0, 0, 0);
                     }
                 }
             }
         }
     };
 
-    // prologue: step s0
+    // The host guarantees an even number of steps per split, so the ring needs no tail; the prefetch of the step
+    // after the last one is clamped (a harmless re-read) rather than branched around: a conditional load makes the
+    // compiler's s_waitcnt placement assume the short path and wait for the NEW loads on the hot one.
     issue_g(s0, g[0]);
     issue_r(s0);
     stage_r(0);
@@ -306,16 +313,16 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
     for (int s = s0; s < s1; s += 2) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (s + k < s1) {
-                const bool more = s + k + 1 < s1;
-                if (more) {
-                    issue_g(s + k + 1, g[k ^ 1]);
-                    issue_r(s + k + 1);
-                }
-                compute(g[k], k);
-                if (more) stage_r(k ^ 1);
-                __syncthreads();
-            }
+            const int nxt = min(s + k + 1, s1 - 1);
+            // R image first (L2-resident, needed at the end of this step), packed words last: waiting for the
+            // former then leaves the HBM loads of the next step in flight (the vector-memory queue is in-order).
+            issue_r(nxt);
+            issue_g(nxt, g[k ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE the MFMA block (LLVM sinks it otherwise)
+            compute(g[k], k);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_r(k ^ 1);
+            __syncthreads();
         }
     }
     // D: lane holds rows 4q + reg (entry), col r
@@ -531,18 +538,23 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const uint8_t* __restrict__ 
         }
     };
 
+    // ring prologue / steady state / tail.  Prefetches past the end are clamped to the last step (harmless re-reads)
+    // instead of branched around: a conditional load makes the compiler wait for the NEW loads on the hot path.
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
-        if (kb0 + s < kb1) issue(kb0 + s, w[s], a[s], fl[s]);
-    for (int kb = kb0; kb < kb1; kb += NS) {
+    for (int s = 0; s < NS; ++s) issue(min(kb0 + s, kb1 - 1), w[s], a[s], fl[s]);
+    int kb = kb0;
+    for (; kb + NS <= kb1; kb += NS) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            if (kb + s < kb1) {
-                compute(w[s], a[s], fl[s]);
-                if (kb + s + NS < kb1) issue(kb + s + NS, w[s], a[s], fl[s]);
-            }
+            compute(w[s], a[s], fl[s]);
+            __builtin_amdgcn_sched_barrier(0);      // refill the stage right here, not wherever the scheduler sinks it
+            issue(min(kb + s + NS, kb1 - 1), w[s], a[s], fl[s]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (kb + s < kb1) compute(w[s], a[s], fl[s]);
     // D[row = column c = 4q + reg][col = n]; for MFMA (iw, u) the sample is (256 IW) grp + (16 IW) n + 16 iw + u:
     // a lane owns 16*IW consecutive samples per (tile, reg).
     const int64_t i0 = grp * (256 * IW) + n * NU;
@@ -954,7 +966,8 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                 const int n_steps = n_chunks / 2;                 // 512-sample steps (pitch is a multiple of 256 B)
                 int splits = (768 + gx - 1) / gx;
                 splits = std::max(1, std::min(splits, n_steps / 4 > 0 ? n_steps / 4 : 1));
-                const int cps = (n_steps + splits - 1) / splits;  // steps per split
+                int cps = (n_steps + splits - 1) / splits;        // steps per split, even (n_steps is even)
+                cps += cps & 1;
                 splits = (n_steps + cps - 1) / cps;
                 ProfScope ps(e, stream, 0);
 #define G1(NTL_, PARTS_, EX_) launch_gemm1<NTL_, PARTS_, EX_>(e, packed, rows, n, fill, n_steps, cps, splits, stream)
