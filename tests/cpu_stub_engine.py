@@ -1,0 +1,68 @@
+"""A CPU stand-in with the SketchEngine interface, built from ORACLE math, for the multi-process (gloo) tests of
+the streaming driver's sharding / all-reduce / gather logic.  Test infrastructure only: the product never
+constructs it (``pyrhe_amd`` has no CPU path)."""
+import numpy as np
+import torch
+
+from oracle import plink
+from oracle import rhe_oracle as O
+
+
+class CpuStubEngine:
+    def __init__(self, n_orig, n_keep):
+        self.n_samples_orig = n_orig
+        self.n_keep = n_keep
+        self.pitch = (plink.row_bytes(n_orig) + 255) // 256 * 256
+        self.n_pad = 4 * self.pitch
+        self.sub_snps = 1 << 20
+
+    def keep_vector(self, missing=()):
+        k = torch.zeros(self.n_pad, dtype=torch.float32)
+        k[: self.n_samples_orig] = 1
+        if len(missing):
+            k[list(missing)] = 0
+        return k
+
+    def set_rhs(self, sketch_cols, norm_cols, keep):
+        self.sk = None if sketch_cols is None else sketch_cols.double().numpy()
+        self.nm = None if norm_cols is None else norm_cols.double().numpy()
+        self.keep = keep.numpy().astype(bool)
+        self.n_sketch = 0 if self.sk is None else self.sk.shape[0]
+        self.n_norm = 0 if self.nm is None else self.nm.shape[0]
+
+    def block_stats(self, packed):
+        codes = plink.decode_codes(packed.numpy(), self.n_pad)[:, self.keep]
+        g = np.array([0, 0, 1, 2])[codes]
+        return torch.from_numpy(g.sum(1).astype(np.int32)), torch.from_numpy((codes == 1).sum(1).astype(np.int32))
+
+    def sketch_block(self, packed, entries, offsets, *, fill=None, out_sketch=None, out_norm=None, accumulate=False,
+                     want_colsum=False):
+        nbin = len(offsets) - 1
+        if out_sketch is None:
+            out_sketch = torch.zeros((nbin, self.n_sketch, self.n_pad), dtype=torch.float32)
+        if out_norm is None:
+            out_norm = torch.zeros((nbin, max(self.n_norm, 1)), dtype=torch.float64)
+        G = plink.decode_count_a2(packed.numpy(), self.n_pad).T.astype(np.float64)       # [m, n_pad]
+        if fill is not None:
+            f = fill.numpy()
+            for r in range(G.shape[0]):
+                G[r, np.isnan(G[r])] = f[r]
+        ent = entries.numpy()
+        for b in range(nbin):
+            rows = ent[offsets[b]:offsets[b + 1]]
+            sk = np.zeros((self.n_sketch, self.n_pad))
+            nm = np.zeros(max(self.n_norm, 1))
+            if len(rows):
+                Gk = G[rows][:, self.keep].astype(np.float32)
+                X = O.standardize_geno(np.asfortranarray(Gk.T)).astype(np.float64)          # [N, m] reference arithmetic
+                if self.n_sketch:
+                    sk[:, self.keep] = (X @ (X.T @ self.sk[:, self.keep].T)).T
+                if self.n_norm:
+                    nm[: self.n_norm] = ((X.T @ self.nm[:, self.keep].T) ** 2).sum(axis=0)
+            if accumulate:
+                out_sketch[b] += torch.from_numpy(sk).float()
+                out_norm[b] += torch.from_numpy(nm)
+            else:
+                out_sketch[b] = torch.from_numpy(sk).float()
+                out_norm[b] = torch.from_numpy(nm)
+        return out_sketch, out_norm, None
