@@ -94,6 +94,11 @@ CASES = [
          kw=dict(num_jack=5, num_random_vec=10, seed=6)),
     dict(name="genie_gxe_2bin", cohort=dict(n_indv=403, n_snp=240, seed=18, nbin=2, with_env=True), model="GENIE",
          kw=dict(num_jack=10, num_random_vec=10, seed=7, genie_model="G+GxE")),
+    dict(name="genie_gxe_nxe_2bin", cohort=dict(n_indv=403, n_snp=240, seed=20, nbin=2, with_env=True), model="GENIE",
+         kw=dict(num_jack=10, num_random_vec=10, seed=9, genie_model="G+GxE+NxE")),
+    dict(name="genie_gxe_nxe_cov", cohort=dict(n_indv=403, n_snp=240, seed=21, nbin=1, with_env=True, with_cov=3), model="GENIE",
+         kw=dict(num_jack=10, num_random_vec=10, seed=10, genie_model="G+GxE+NxE")),
+    # genie_model="G" has no reference behaviour: GENIE.aggregate indexes env[:, -1 - 2*nbin] and raises IndexError
     dict(name="genie_gxe_cov", cohort=dict(n_indv=403, n_snp=240, seed=19, nbin=1, with_env=True, with_cov=3), model="GENIE",
          kw=dict(num_jack=10, num_random_vec=10, seed=8, genie_model="G+GxE")),
 ]

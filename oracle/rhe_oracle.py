@@ -172,15 +172,26 @@ class Problem:
         return self.annot.shape[1]
 
     @property
+    def has_gxe(self) -> bool:
+        return self.genie_model in ("G+GxE", "G+GxE+NxE")
+
+    @property
+    def has_nxe(self) -> bool:
+        return self.genie_model == "G+GxE+NxE"
+
+    @property
     def n_est(self) -> int:
-        return self.nbin * (2 if self.genie_model == "G+GxE" else 1)
+        """genie.py:26-34 (one environment)."""
+        return self.nbin * (2 if self.has_gxe else 1) + (1 if self.has_nxe else 0)
 
     def len_bin(self) -> np.ndarray:
         return (self.annot == 1).sum(axis=0)
 
     def m_last_row(self) -> np.ndarray:
+        """genie.py:36-44."""
         lb = self.len_bin()
-        return np.concatenate([lb, lb]) if self.genie_model == "G+GxE" else lb
+        parts = [lb] + ([lb] if self.has_gxe else []) + ([np.ones(1, lb.dtype)] if self.has_nxe else [])
+        return np.concatenate(parts)
 
 
 def make_probe_vectors(seed: int, n_indv: int, k: int) -> np.ndarray:
@@ -231,7 +242,7 @@ def sketch_block(p: Problem, j: int, reseed: bool) -> BlockSketch:
 
     for b_idx, Gb in enumerate(bins):
         one(b_idx, standardize_geno(Gb))
-    if p.genie_model == "G+GxE":                        # genie.py:59-75 ; k_gxe = (e+1)*k + nbin, e = 0
+    if p.has_gxe:                                       # genie.py:59-75 ; k_gxe = (e+1)*k + nbin, e = 0
         for b_idx, Gb in enumerate(bins):
             Xs = standardize_geno(Gb)
             Xe = (_t32(Xs) * _t32(p.env.reshape(-1, 1))).numpy()   # elem_mul, mat_mul.py:34-47
@@ -471,10 +482,10 @@ def rhe_results(p: Problem, st: State, method: str = "QR") -> dict:
 
 
 # --------------------------------------------------------------------------- GENIE result shaping
-def genie_h2(sig_adj_all: np.ndarray, nbin: int, n_gxe: int) -> np.ndarray:
-    """GENIE G+GxE h2 rows (genie.py:146-189): per-bin g, per-bin gxe, total, total_g, total_gxe."""
+def genie_h2(sig_adj_all: np.ndarray, nbin: int, n_gxe: int, n_nxe: int = 0) -> np.ndarray:
+    """GENIE h2 rows (genie.py:146-189): per-bin g, per-bin gxe, nxe, total, total_g, [total_gxe]."""
     rows = []
-    ne = nbin + n_gxe
+    ne = nbin + n_gxe + n_nxe
     for s in sig_adj_all:
         tv = 0
         for e in range(ne):
@@ -482,13 +493,17 @@ def genie_h2(sig_adj_all: np.ndarray, nbin: int, n_gxe: int) -> np.ndarray:
         den = tv + s[-1]
         g = [s[i] / den for i in range(nbin)]
         x = [s[nbin + i] / den for i in range(n_gxe)]
+        nx = [s[nbin + n_gxe + i] / den for i in range(n_nxe)]
         gt = 0
         for v in g:
             gt += v
         xt = 0
         for v in x:
             xt += v
-        row = g + x + [gt + xt + 0, gt]
+        nt = 0
+        for v in nx:
+            nt += v
+        row = g + x + nx + [gt + xt + nt, gt]
         if n_gxe:
             row.append(xt)
         rows.append(row)
@@ -513,8 +528,8 @@ def genie_results(p: Problem, st: State, method: str = "QR") -> dict:
     """The result dict of ``GENIE.run`` (genie.py:221-301)."""
     sj, stot, sja, stota, Ts, qs = estimate(p, st, method)
     jn, nbin = p.n_jack, p.nbin
-    n_gxe = p.n_est - nbin
-    h2 = genie_h2(np.vstack([sja, stota[None]]), nbin, n_gxe)
+    n_gxe = nbin if p.has_gxe else 0
+    h2 = genie_h2(np.vstack([sja, stota[None]]), nbin, n_gxe, 1 if p.has_nxe else 0)
     enr = genie_enrichment(h2, st.M[-1], nbin)
     return {
         "sigma_ests_total": stot, "sig_errs": jackknife_se(sj, jn),

@@ -234,3 +234,124 @@ class RHE(Base):
 class StreamingRHE(RHE):
     """``pyrhe/src/models/rhe/streaming_rhe.py`` semantics (one-worker streaming; quirk Q4 unless compat='fixed')."""
     streaming = True
+
+
+class GENIE(Base):
+    """Gene-environment model (``pyrhe/src/models/genie/genie.py``): G, G+GxE or G+GxE+NxE with ONE environment
+    column named ``env``.  Non-streaming semantics, including the reference's treatment of the last estimate of
+    "G+GxE" as the heteroscedastic-noise term (genie.py:18 with base.py:467-481) unless ``compat="fixed"``.
+    ``genie_model="G"`` raises IndexError in the reference's aggregate; here it is the plain G model."""
+
+    def __init__(self, env_file: str = None, genie_model: str = "G+GxE+NxE", **kwargs):
+        super().__init__(**kwargs)
+        if genie_model not in ("G", "G+GxE", "G+GxE+NxE"):
+            raise ValueError("Unsupported GENIE genie_model type")
+        self.num_env, env = rio.read_env(env_file)
+        # the reference keeps the env rows of dropped individuals (and then fails to broadcast); this build drops them
+        self.env = np.delete(np.asarray(env, dtype=np.float64), self.missing_indv, axis=0)
+        self.num_gen_env_bin = self.num_bin * self.num_env
+        self.genie_model = genie_model
+        self.log._log(f"Number of environments: {self.num_env}")
+        self.log._log(f"GENIE model: {self.genie_model}")
+        has_gxe = genie_model in ("G+GxE", "G+GxE+NxE")
+        n_cols = (2 if self.use_cov else 1) * self.num_random_vec * (2 if has_gxe else 1) + (2 if has_gxe else 1)
+        self._engines = [self.engine]
+        if n_cols > 30:      # GxE with covariates: [Z, UZ | y] and [e.Z, e.UZ | e.y] go through two engines
+            self._engines.append(SketchEngine(self.num_indv_original, self.num_indv, max_entries=self.plan.max_block,
+                                              precision=self.precision, device=self.device))
+
+    def get_num_estimates(self):
+        if self.genie_model == "G":
+            return self.num_bin
+        if self.genie_model == "G+GxE":
+            return self.num_bin + self.num_gen_env_bin
+        return self.num_bin + self.num_gen_env_bin + self.num_env
+
+    def get_M_last_row(self):
+        if self.genie_model == "G":
+            return self.len_bin
+        if self.genie_model == "G+GxE":
+            return np.concatenate((self.len_bin, self.len_bin * self.num_env))
+        return np.concatenate((self.len_bin, self.len_bin * self.num_env, [1] * self.num_env))
+
+    def _make_runner(self) -> SketchRunner:
+        return SketchRunner(self._engines, self.geno_dev, self.plan, self.local_blocks, n_orig=self.num_indv_original,
+                            missing_indv=self.missing_indv, Z=self.all_zb, cov=self.cov_matrix, env=self.env,
+                            genie_model=self.genie_model, impute=self.geno_impute_methods, seed=self.seed,
+                            streaming=self.streaming, compat=self.compat, recompute_pass2=self.recompute_pass2,
+                            rng_prefix_draws=self._rng_prefix)
+
+    def estimate(self, method: str = "lstsq"):
+        """Variance components and their trace-adjusted copies sigma_i * T[i, ne] (genie.py:97-144)."""
+        ne = self.num_estimates
+        rows, adj = [], []
+        for j in range(self.num_jack + 1):
+            T = self.systems.T[j]
+            s = est.solve_normal_equations(T, self.systems.q[j].reshape(-1, 1), method)
+            rows.append(s)
+            adj.append([s[i] * T[i, ne] for i in range(len(s))])
+        rows, adj = np.array(rows), np.array(adj)
+        return rows[:-1, :], rows[-1, :], adj[:-1, :], adj[-1, :]
+
+    def run(self, method):
+        log = self.log._log
+        nb, ng, nv = self.num_bin, self.num_gen_env_bin, self.num_env
+        has_gxe = self.genie_model in ("G+GxE", "G+GxE+NxE")
+        has_nxe = self.genie_model == "G+GxE+NxE"
+        sigma_jack, sigma_total, adj_jack, adj_total = self.estimate(method=method)
+        sig_errs = self.estimate_error(sigma_jack)
+        log("Variance components: ")
+        for i, v in enumerate(sigma_total):
+            last = i == len(sigma_total) - 1
+            if self.genie_model == "G":
+                if not last:
+                    log(f"Sigma^2_g[{i}] : {v}  SE : {sig_errs[i]}")
+            elif self.genie_model == "G+GxE":
+                # the reference's loop has no upper bound here, so sigma_e is ALSO echoed as the last "gxe" line
+                # (genie.py:232-236); kept for log compatibility
+                if i < nb:
+                    log(f"Sigma^2_g[{i}] : {v}  SE : {sig_errs[i]}")
+                else:
+                    log(f"Sigma^2_gxe[{i - nb}] : {v}  SE : {sig_errs[i]}")
+            else:
+                if i < nb:
+                    log(f"Sigma^2_g[{i}] : {v}  SE : {sig_errs[i]}")
+                elif i < nb + ng:
+                    log(f"Sigma^2_gxe[{i - nb}] : {v}  SE : {sig_errs[i]}")
+                elif i < nb + ng + nv:
+                    log(f"Sigma^2_nxe[{i - nb - ng}] : {v}  SE : {sig_errs[i]}")
+        log(f"Sigma^2_e : {sigma_total[-1]}  SE : {sig_errs[-1]}")
+        h2_jack, h2_total = est.genie_h2(adj_jack, adj_total, nb, ng if has_gxe else 0, nv if has_nxe else 0)
+        h2_errs = self.estimate_error(h2_jack)
+        log("*****")
+        log("Heritabilities:")
+        n_comp = nb + (ng if has_gxe else 0) + (nv if has_nxe else 0)
+        for i, v in enumerate(h2_total):
+            if i < nb:
+                log(f"h2_g[{i}] : {v} SE : {h2_errs[i]}")
+            elif has_gxe and i < nb + ng:
+                log(f"h2_gxe[{i - nb}] : {v} SE : {h2_errs[i]}")
+            elif has_nxe and i < n_comp:
+                log(f"h2_nxe[{i - nb - ng}] : {v} SE : {h2_errs[i]}")
+            elif i == n_comp:
+                log(f"Total h2 : {v} SE: {h2_errs[i]}")
+            elif i == n_comp + 1:
+                log(f"Total h2_g : {v} SE: {h2_errs[i]}")
+            elif i == n_comp + 2:
+                log(f"Total h2_gxe : {v} SE: {h2_errs[i]}")
+        log("*****")
+        log("Enrichments:")
+        enr_jack, enr_total = est.genie_enrichment(h2_jack, h2_total, self.M[-1], nb)
+        enr_errs = self.estimate_error(enr_jack)
+        for i, v in enumerate(enr_total):
+            log(f"Enrichment g[{i}] : {v} SE : {enr_errs[i]}")
+        self.sigma_est_jackknife = sigma_jack
+        return {"sigma_ests_total": sigma_total, "sig_errs": sig_errs, "h2_total": h2_total, "h2_errs": h2_errs,
+                "enrichment_total": enr_total, "enrichment_errs": enr_errs}
+
+
+class StreamingGENIE(GENIE):
+    """``pyrhe/src/models/genie/streaming_genie.py`` semantics (one-worker streaming).  The reference's streaming
+    aggregate raises for "G+GxE" (base_streaming.py:45-46 indexes one estimate too far); here that model simply has
+    no N x E term."""
+    streaming = True

@@ -95,17 +95,23 @@ class Systems:
 class SketchRunner:
     """Pass 1 (sketch every local block, accumulate, all-reduce) and pass 2 (leave-one-out systems).
 
-    ``engine`` is a :class:`pyrhe_amd.engine.SketchEngine` (or anything with its ``set_rhs/sketch_block/
-    block_stats/keep_vector`` interface: the multi-process CPU tests inject a stand-in, the product never does).
-    ``geno`` holds the packed rows of THIS rank's blocks ``[j0, j1)`` on the device, first row = ``range(j0)[0]``.
+    ``engines``: one :class:`pyrhe_amd.engine.SketchEngine`, or two when the right-hand columns do not fit one
+    engine (GENIE G x E with covariates: [Z, UZ | y] and [e.Z, e.UZ | e.y]).  Anything with the engine's
+    ``set_rhs/sketch_block/block_stats/keep_vector`` interface works: the multi-process CPU tests inject a
+    stand-in, the product never does.  ``geno`` holds the packed rows of THIS rank's blocks ``[j0, j1)`` on the
+    device, first row = ``range(j0)[0]``.
+
+    Estimates (rows of the normal equations), in the reference's order (genie.py:26-44): one per annotation bin
+    (G), then one per bin for G x E, then one N x E term.
     """
 
-    def __init__(self, engine, geno: torch.Tensor, plan: BlockPlan, local_blocks: Tuple[int, int], *,
+    def __init__(self, engines, geno: torch.Tensor, plan: BlockPlan, local_blocks: Tuple[int, int], *,
                  n_orig: int, missing_indv: Sequence[int], Z: np.ndarray, cov: Optional[np.ndarray] = None,
                  env: Optional[np.ndarray] = None, genie_model: Optional[str] = None,
                  impute: str = "binary", seed: int = 0, streaming: bool = True, compat: str = "reference",
                  recompute_pass2: bool = False, rng_prefix_draws: int = 0, group=None):
-        self.eng = engine
+        self.engs = list(engines) if isinstance(engines, (list, tuple)) else [engines]
+        self.eng = self.engs[0]
         self.geno = geno
         self.plan = plan
         self.j0, self.j1 = local_blocks
@@ -117,6 +123,8 @@ class SketchRunner:
         self.k = self.Z.shape[1]
         self.cov = None if cov is None else np.asarray(cov, np.float64)
         self.env = None if env is None else np.asarray(env, np.float64).reshape(-1)
+        if genie_model not in (None, "G", "G+GxE", "G+GxE+NxE"):
+            raise ValueError("Unsupported GENIE genie_model type")
         self.genie_model = genie_model
         self.impute = impute
         self.seed = int(seed)
@@ -130,12 +138,19 @@ class SketchRunner:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.device = geno.device
-        self.n_pad = engine.n_pad
+        self.n_pad = self.eng.n_pad
         self.row0 = plan.range(self.j0)[0] if self.j1 > self.j0 else 0
         self._keep_t = torch.as_tensor(self.keep_idx, device=self.device)
-        self.keep = engine.keep_vector(self.missing)
-        self.n_gxe = plan.n_bin if genie_model in ("G+GxE", "G+GxE+NxE") else 0
-        self.n_est = plan.n_bin + self.n_gxe
+        self.keep = self.eng.keep_vector(self.missing)
+        nb = plan.n_bin
+        self.n_gxe = nb if genie_model in ("G+GxE", "G+GxE+NxE") else 0
+        self.n_nxe = 1 if genie_model == "G+GxE+NxE" else 0
+        self.n_est = nb + self.n_gxe + self.n_nxe
+        # Reference quirk (base.py:467,472-481): the NON-streaming GENIE treats its LAST estimate as the
+        # heteroscedastic-noise term for every genie_model (GENIE sets num_env = 1, genie.py:18), so for "G+GxE" the
+        # whole-data slot of the last GxE bin is overwritten by the N x E sketch.  ("G" raises IndexError there and
+        # the streaming aggregate raises for "G+GxE" (base_streaming.py:45-46), so those have no reference behaviour.)
+        self.quirk_last_total = genie_model == "G+GxE" and (not self.streaming) and compat == "reference"
         # covariate projector pieces (base.py:151,177-178)
         if self.cov is not None:
             W = self.cov
@@ -147,8 +162,11 @@ class SketchRunner:
             self.Q32 = self.Q64.to(torch.float32)
             self.UZ64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.UZ.T)))  # [k, n_pad]
         self.Z64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.Z.T)))        # [k, n_pad] f64
+        if self.env is not None:
+            self.env_pad = self._pad_cols(torch.from_numpy(self.env[None, :]))[0]            # [n_pad] f64
         self._entries_cache = {}
         self._stats = None
+        self._check_missing = True
         self.timings = {}
 
     # ---- padding helpers: kept samples -> their original positions, zeros elsewhere
@@ -164,32 +182,50 @@ class SketchRunner:
 
     # ---- right-hand sides ---------------------------------------------------------------------
     def _install_rhs(self, y: np.ndarray):
-        """Columns handed to the engine.  Sketch groups (k columns each): Z, [UZ], [e.Z]; norm: y~, [e.y~]."""
-        k = self.k
-        groups = [self.Z64]
-        self.g_Z, self.g_UZ, self.g_eZ = 0, None, None
-        if self.cov is not None:
-            self.g_UZ = len(groups)
-            groups.append(self.UZ64)
+        """Columns handed to the engine(s).  Sketch groups of k columns: Z, [UZ] and for G x E e.Z, [e.UZ];
+        norm columns: y~ and e.y~  (X_e^T r = X^T (e . r), X_e v = e . (X v); streaming_genie.py:33-49)."""
+        use_cov = self.cov is not None
         y64 = np.asarray(y, np.float64).reshape(-1)
-        if self.cov is not None:          # regress_pheno (base.py:396-401), float64 on the host
+        if use_cov:          # regress_pheno (base.py:396-401), float64 on the host
             W = self.cov
             y64 = y64 - W @ (np.linalg.pinv(W.T @ W) @ (W.T @ y64))
         self.y_res = y64
-        norms = [self._pad_cols(torch.from_numpy(y64[None, :]))]
+        ypad = self._pad_cols(torch.from_numpy(y64[None, :]))
+        g_groups = [self.Z64] + ([self.UZ64] if use_cov else [])
+        passes = [(g_groups, [ypad])]
         if self.n_gxe:
-            e64 = self._pad_cols(torch.from_numpy(self.env[None, :]))
-            self.env_pad = e64[0]
-            self.g_eZ = len(groups)
-            groups.append(self.Z64 * e64)
-            if self.cov is not None:
-                raise NotImplementedError("GENIE G+GxE with covariates needs > 30 right-hand columns")
-            norms.append(norms[0] * e64)
-        sk = torch.cat(groups, dim=0).to(torch.float32)
-        nm = torch.cat(norms, dim=0).to(torch.float32)
-        self.eng.set_rhs(sk, nm, self.keep)
-        self.n_sketch = sk.shape[0]
-        self.n_norm = nm.shape[0]
+            e = self.env_pad
+            e_groups = [self.Z64 * e] + ([self.UZ64 * e] if use_cov else [])
+            passes.append((e_groups, [ypad * e]))
+        max_cols = 30
+        total = sum(sum(g.shape[0] for g in gs) + len(ns) for gs, ns in passes)
+        if len(passes) == 2 and total <= max_cols:
+            passes = [(passes[0][0] + passes[1][0], passes[0][1] + passes[1][1])]
+        if len(passes) > len(self.engs):
+            raise RuntimeError(f"{total} right-hand columns need {len(passes)} engines, {len(self.engs)} given")
+        # where each logical group lives: (pass index, first sketch column) ; norm: (pass index, column)
+        self.loc = {}
+        self.pass_shapes = []
+        for pi, (gs, ns) in enumerate(passes):
+            sk = torch.cat(gs, dim=0).to(torch.float32)
+            nm = torch.cat(ns, dim=0).to(torch.float32)
+            self.engs[pi].set_rhs(sk, nm, self.keep)
+            self.pass_shapes.append((sk.shape[0], nm.shape[0]))
+        k = self.k
+        ng = len(g_groups)
+        self.loc["Z"], self.loc["y"] = (0, 0), (0, 0)
+        if use_cov:
+            self.loc["UZ"] = (0, k)
+        if self.n_gxe:
+            if len(passes) == 1:
+                self.loc["eZ"], self.loc["ey"] = (0, ng * k), (0, 1)
+                if use_cov:
+                    self.loc["eUZ"] = (0, (ng + 1) * k)
+            else:
+                self.loc["eZ"], self.loc["ey"] = (1, 0), (1, 0)
+                if use_cov:
+                    self.loc["eUZ"] = (1, k)
+        self.n_pass = len(passes)
 
     # ---- imputation fill values ---------------------------------------------------------------
     def _block_rows(self, j: int) -> torch.Tensor:
@@ -243,10 +279,9 @@ class SketchRunner:
             self._entries_cache[j] = (torch.from_numpy(cat).to(self.device), offs)
         return self._entries_cache[j]
 
-    def sketch_local_blocks(self, out_sk: Optional[torch.Tensor], out_norm: Optional[torch.Tensor],
-                            totals_sk: Optional[torch.Tensor] = None, pass_index: int = 0):
-        """Enqueue the sketch of every local block.  ``out_sk [jl, nbin, n_sketch, n_pad]`` receives the per-block
-        sketches (or, if None, ``totals_sk [nbin, n_sketch, n_pad]`` float32 is accumulated in place)."""
+    def sketch_local_blocks(self, out_sk, out_norm, pass_index: int = 0):
+        """Enqueue the sketch of every local block: ``out_sk[p][jl]`` / ``out_norm[p][jl]`` receive the per-block
+        outputs of engine pass p (``[nbin, n_sketch_p, n_pad]`` float32 / ``[nbin, n_norm_p]`` float64)."""
         any_missing = bool(self._check_missing and self._ingest_stats()[1].any())
         draw = self._uniform_stream(pass_index) if any_missing else None
         for jl, j in enumerate(range(self.j0, self.j1)):
@@ -256,12 +291,9 @@ class SketchRunner:
             if any_missing:
                 u = draw(j, e - s)                    # one uniform per SNP, missing or not (base.py:266,285)
                 fill = self._fill_for_block(j, u)
-            if out_sk is not None:
-                self.eng.sketch_block(self._block_rows(j), ent, offs, fill=fill, out_sketch=out_sk[jl],
-                                      out_norm=out_norm[jl], accumulate=False)
-            else:
-                self.eng.sketch_block(self._block_rows(j), ent, offs, fill=fill, out_sketch=totals_sk,
-                                      out_norm=out_norm[jl], accumulate=True)
+            for p in range(self.n_pass):
+                self.engs[p].sketch_block(self._block_rows(j), ent, offs, fill=fill, out_sketch=out_sk[p][jl],
+                                          out_norm=out_norm[p][jl], accumulate=False)
 
     def _apply_U(self, v: torch.Tensor, f32: bool) -> torch.Tensor:
         """``W (Q (W^T v))`` for rows of v ``[..., n_pad]``; float32 like _compute_UXXz (base.py:407-408) or float64
@@ -285,76 +317,151 @@ class SketchRunner:
         self._check_missing = check_missing
         self._install_rhs(y)
         dev = self.device
-        self.blocks_sk = torch.empty((jl, nb, self.n_sketch, self.n_pad), dtype=torch.float32, device=dev)
-        self.blocks_nm = torch.zeros((max(jl, 1), nb, self.n_norm), dtype=torch.float64, device=dev)
+        self.blocks_sk = [torch.empty((jl, nb, ns, self.n_pad), dtype=torch.float32, device=dev) for ns, _ in self.pass_shapes]
+        self.blocks_nm = [torch.zeros((max(jl, 1), nb, nn), dtype=torch.float64, device=dev) for _, nn in self.pass_shapes]
+
+    # ---- estimate-level views of one block's (or the total's) engine outputs ----------------------
+    def _group(self, sk_list, name):
+        p, c0 = self.loc[name]
+        return sk_list[p][:, c0:c0 + self.k]
+
+    def _block_estimates(self, sk_list, nm_list):
+        """A = XXz, C = XXUz ``[ne_g, k, n_pad]`` and r = yXXy ``[ne_g]`` of the genotype-derived estimates (G bins,
+        then G x E bins) from engine outputs of one block; float64."""
+        f64 = torch.float64
+        A = self._group(sk_list, "Z").to(f64)
+        C = self._group(sk_list, "UZ").to(f64) if self.cov is not None else None
+        py, cy = self.loc["y"]
+        r = nm_list[py][:, cy]
+        if self.n_gxe:
+            e = self.env_pad
+            # elem_mul(X, env) then float32 GEMVs in the reference (streaming_genie.py:39-41): X_e X_e^T z = e.(X X^T (e.z))
+            Ae = (self._group(sk_list, "eZ") * e.to(torch.float32)).to(f64)
+            A = torch.cat([A, Ae], dim=0)
+            if C is not None:
+                Ce = (self._group(sk_list, "eUZ") * e.to(torch.float32)).to(f64)
+                C = torch.cat([C, Ce], dim=0)
+            pe, ce = self.loc["ey"]
+            r = torch.cat([r, nm_list[pe][:, ce]], dim=0)
+        return A, C, r
+
+    def _nxe_sketch(self):
+        """Closed form of the N x E sketch the reference builds from an N x N diagonal (base_streaming.py:45-58,
+        SURVEY Q10): XXz = fp32(e . fp32(e . z)), yXXy = ||e . y~||^2, XXUz likewise with UZ."""
+        f32, f64 = torch.float32, torch.float64
+        e32 = self.env_pad.to(f32)
+        A = (e32 * (e32 * self.Z64.to(f32))).to(f64)[None]                 # [1, k, n_pad]
+        ypad = self._pad_cols(torch.from_numpy(self.y_res[None, :]))[0]
+        v = e32 * ypad.to(f32)
+        r = (v.to(f64) @ v.to(f64)).to(f32).to(f64).reshape(1)
+        C = (e32 * (e32 * self.UZ64.to(f32))).to(f64)[None] if self.cov is not None else None
+        return A, C, r
 
     def pass1(self):
         """One streaming sketch pass over the local blocks (base_streaming.py:85-104) + aggregate
         (base_streaming.py:21-58 / base.py:465-500: float64 sums in block order) + the cross-GPU all-reduce."""
-        plan, k, nb = self.plan, self.k, self.plan.n_bin
+        plan, k = self.plan, self.k
         jn, jl, dev = plan.n_jack, self.j1 - self.j0, self.device
-        blocks_sk, blocks_nm = self.blocks_sk, self.blocks_nm
-        self.sketch_local_blocks(blocks_sk, blocks_nm, pass_index=0)
-        tot_sk = torch.zeros((nb, self.n_sketch, self.n_pad), dtype=torch.float64, device=dev)
-        tot_nm = torch.zeros((nb, self.n_norm), dtype=torch.float64, device=dev)
+        self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0)
+        ne_g = plan.n_bin + self.n_gxe
+        f64 = torch.float64
         use_cov = self.cov is not None
-        D_tot = torch.zeros((nb, k, self.n_pad), dtype=torch.float64, device=dev) if use_cov else None
-        wsum = torch.zeros_like(D_tot) if (use_cov and self.world > 1) else None
+        tot_A = torch.zeros((ne_g, k, self.n_pad), dtype=f64, device=dev)
+        tot_C = torch.zeros_like(tot_A) if use_cov else None
+        tot_r = torch.zeros(ne_g, dtype=f64, device=dev)
+        D_tot = torch.zeros_like(tot_A) if use_cov else None
+        wsum = torch.zeros_like(tot_A) if (use_cov and self.world > 1) else None
         q4 = use_cov and self.streaming and self.compat == "reference"
         for jl_i in range(jl):
-            blk = blocks_sk[jl_i]
-            tot_sk += blk
-            tot_nm += blocks_nm[jl_i]
+            A, C, r = self._block_estimates([b[jl_i] for b in self.blocks_sk], [b[jl_i] for b in self.blocks_nm])
+            tot_A += A
+            tot_r += r
             if use_cov:
+                tot_C += C
                 if q4 and self.world == 1:
                     # quirk Q4 (streaming_rhe.py:18-21): U applied to the RUNNING sum of XXz, float32
-                    D_tot += self._apply_U(tot_sk[:, :k], f32=True)
+                    D_tot += self._apply_U(tot_A, f32=True)
                 elif q4:
-                    wsum += blk[:, :k].to(torch.float64) * float(jn - (self.j0 + jl_i))
+                    wsum += A * float(jn - (self.j0 + jl_i))
                 else:
-                    D_tot += self._apply_U(blk[:, :k], f32=True)
+                    D_tot += self._apply_U(A, f32=True)
         if self.world > 1:
-            self._allreduce(tot_sk)
-            self._allreduce(tot_nm)
+            self._allreduce(tot_A)
+            self._allreduce(tot_r)
             if use_cov:
+                self._allreduce(tot_C)
                 if q4:   # U is linear: sum_j U(running_j) = U(sum_j (jn - j) XXz_j)  (float32 rounding order differs)
                     self._allreduce(wsum)
                     D_tot = self._apply_U(wsum, f32=True)
                 else:
                     self._allreduce(D_tot)
-        self.tot_sk, self.tot_nm, self.D_tot = tot_sk, tot_nm, D_tot
+        self.tot_A, self.tot_C, self.tot_r, self.D_tot = tot_A, tot_C, tot_r, D_tot
+        self.tot_sk = tot_A            # [n_est_g, k, n_pad] float64 (kept under the old name for callers)
 
     def pass2(self) -> Systems:
         """Leave-one-out normal equations where each block lives (base_streaming.py:110-144), gathered to every rank."""
         plan, k, ne = self.plan, self.k, self.n_est
-        jn = plan.n_jack
+        jn, nb = plan.n_jack, plan.n_bin
         use_cov = self.cov is not None
-        tot_sk, tot_nm, D_tot = self.tot_sk, self.tot_nm, self.D_tot
-        # M (rhe.py:16): SNPs of every estimate outside block j
+        # M (rhe.py:16, genie.py:36-44,77-82): SNPs of every estimate outside block j; the N x E term counts 1
         M = np.zeros((jn + 1, ne), np.int64)
-        last = np.concatenate([plan.len_bin, plan.len_bin]) if self.n_gxe else plan.len_bin
+
+        def row(c):
+            parts = [c] + ([c] if self.n_gxe else []) + ([np.ones(1, np.int64)] if self.n_nxe else [])
+            return np.concatenate(parts)
+        last = row(plan.len_bin)
         M[jn] = last
         for j in range(jn):
-            c = plan.block_counts(j)
-            M[j] = last - (np.concatenate([c, c]) if self.n_gxe else c)
+            blk = row(plan.block_counts(j))
+            if self.n_nxe:
+                blk[-1] = 0
+            M[j] = last - blk
         yy = float(self.y_res @ self.y_res)
+
+        tot_A, tot_C, tot_r, D_tot = self.tot_A, self.tot_C, self.tot_r, self.D_tot
+        nxe = self._nxe_sketch() if (self.n_nxe or self.quirk_last_total) else None
+        if self.quirk_last_total:
+            # whole-data slot of the LAST estimate := N x E sketch; its UXXz / XXUz only for the last probe vector
+            # (base.py:472-481: the covariate lines sit outside the loop over b)
+            tot_A, tot_r = tot_A.clone(), tot_r.clone()
+            tot_A[-1], tot_r[-1] = nxe[0][0], nxe[2][0]
+            if use_cov:
+                tot_C, D_tot = tot_C.clone(), D_tot.clone()
+                tot_C[-1], D_tot[-1] = 0, 0
+                tot_C[-1, k - 1] = nxe[1][0, k - 1]
+                D_tot[-1, k - 1] = self._apply_U(nxe[0][0, k - 1], f32=True)
+
+        def with_nxe(A, C, D, r):
+            if not self.n_nxe:
+                return A, C, D, r
+            A = torch.cat([A, nxe[0]], dim=0)
+            r = torch.cat([r, nxe[2]], dim=0)
+            if use_cov:
+                Cn = torch.zeros_like(nxe[0]); Dn = torch.zeros_like(nxe[0])
+                Cn[0, k - 1] = nxe[1][0, k - 1]
+                Dn[0, k - 1] = self._apply_U(nxe[0][0, k - 1], f32=True)
+                C = torch.cat([C, Cn], dim=0)
+                D = torch.cat([D, Dn], dim=0)
+            return A, C, D, r
+
         local = []
         for jl_i, j in enumerate(range(self.j0, self.j1)):
             if self.recompute_pass2:
-                sk, nm, _ = self._resketch(j)
+                sk_l, nm_l = self._resketch(j)
             else:
-                sk, nm = self.blocks_sk[jl_i], self.blocks_nm[jl_i]
+                sk_l, nm_l = [b[jl_i] for b in self.blocks_sk], [b[jl_i] for b in self.blocks_nm]
             slot = jn if (jn == 1 and j == 0) else j          # base.py:654-655
             if slot == jn:
-                T, q = self._system(tot_sk, tot_nm, D_tot, M[jn], yy)
+                T, q = self._system(*with_nxe(tot_A, tot_C, D_tot, tot_r), M[jn], yy)
             else:
-                blk = sk.to(torch.float64)
+                A, C, r = self._block_estimates(sk_l, nm_l)
                 D = None
                 if use_cov:
-                    D = D_tot - self._apply_U(blk[:, :k], f32=True)      # streaming_rhe.py:35-36
-                T, q = self._system(tot_sk - blk, tot_nm - nm, D, M[j], yy)
+                    D = D_tot - self._apply_U(A, f32=True)      # streaming_rhe.py:35-36
+                    C = tot_C - C
+                T, q = self._system(*with_nxe(tot_A - A, C, D, tot_r - r), M[j], yy)
             local.append((j, T, q))
-        T_tot, q_tot = self._system(tot_sk, tot_nm, D_tot, M[jn], yy)
+        T_tot, q_tot = self._system(*with_nxe(tot_A, tot_C, D_tot, tot_r), M[jn], yy)
         if self.world > 1:
             gathered = [None] * self.world
             dist.all_gather_object(gathered, local, group=self.group)
@@ -366,28 +473,16 @@ class SketchRunner:
 
     def _resketch(self, j: int):
         ent, offs = self._entries(j)
-        return self.eng.sketch_block(self._block_rows(j), ent, offs)
+        outs = [self.engs[p].sketch_block(self._block_rows(j), ent, offs) for p in range(self.n_pass)]
+        return [o[0] for o in outs], [o[1] for o in outs]
 
     def _allreduce(self, t: torch.Tensor):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     # ---- normal equations (base.py:568-628) ----------------------------------------------------
-    def _estimate_tensors(self, sk: torch.Tensor, nm: torch.Tensor, D: Optional[torch.Tensor]):
-        """Per-estimate A = XXz, C = XXUz, D = UXXz ``[ne, k, n_pad]`` float64 and r = yXXy ``[ne]``."""
-        k = self.k
-        A = sk[:, 0:k]
-        C = sk[:, self.g_UZ * k:(self.g_UZ + 1) * k] if self.g_UZ is not None else None
-        r = nm[:, 0]
-        if self.n_gxe:
-            e = self.env_pad
-            Ae = sk[:, self.g_eZ * k:(self.g_eZ + 1) * k] * e       # X_e X_e^T z = e . (X X^T (e . z))
-            A = torch.cat([A, Ae], dim=0)
-            r = torch.cat([r, nm[:, 1]], dim=0)
-        return A, C, D, r
-
-    def _system(self, sk, nm, D, M_row, yy: float):
+    def _system(self, A, C, D, r, M_row, yy: float):
+        """A = XXz, C = XXUz, D = UXXz ``[ne, k, n_pad]`` float64, r = yXXy ``[ne]`` of one slot -> (T, q)."""
         ne, k = self.n_est, self.k
-        A, C, D, r = self._estimate_tensors(sk, nm, D)
         A2 = A.reshape(ne, -1)
         gram = (A2 @ A2.T).cpu().numpy()
         use_cov = self.cov is not None
@@ -413,7 +508,7 @@ class SketchRunner:
         for a in range(ne):
             Ma = M_row[a]
             if self.genie_model is not None and a >= self.plan.n_bin:
-                tr = tz_all[a] / (k * Ma)                        # stochastic trace of a GxE kernel (genie.py:85-89)
+                tr = tz_all[a] / (k * Ma)                        # stochastic trace of a GxE / NxE kernel (genie.py:85-89)
             else:
                 tr = self.N                                      # rhe.py:24-26
             if use_cov:

@@ -11,7 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RHE_CASES = ["rhe_1bin_nocov", "rhe_3bin_nocov_rem", "rhe_3bin_cov", "rhe_1bin_missing",
              "rhe_1bin_missing_mean", "rhe_1bin_n1024", "rhe_2bin_jn1", "rhe_1bin_2traits"]
 STREAMING_CASES = ["srhe_3bin_cov"]
-GENIE_CASES = ["genie_gxe_2bin", "genie_gxe_cov"]
+GENIE_CASES = ["genie_gxe_2bin", "genie_gxe_cov", "genie_gxe_nxe_2bin", "genie_gxe_nxe_cov"]
 RESULT_KEYS_RHE = ["sigma_ests_total", "sig_errs", "h2_total", "h2_errs", "enrichment_total", "enrichment_errs",
                    "h2_total_overlap", "h2_errs_overlap", "enrichment_total_overlap", "enrichment_errs_overlap"]
 RESULT_KEYS_GENIE = RESULT_KEYS_RHE[:6]
