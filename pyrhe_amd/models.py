@@ -151,7 +151,30 @@ class Base:
         rows = [est.solve_normal_equations(self.systems.T[j], self.systems.q[j].reshape(-1, 1), method)
                 for j in range(self.num_jack + 1)]
         rows = np.array(rows)
+        if self.get_trace and self.rank == 0:
+            self.get_trace_summary()
         return rows[:-1, :], rows[-1, :]
+
+    def get_trace_summary(self):
+        """``--trace``: stochastic-trace summary statistics, files ``run_<pheno>.MN`` / ``.tr`` in the reference's
+        format (base.py:598-599,827-855): LD_SUM[a,b] = (T[a,b] - N) * M_a * M_b / N^2 per jackknife row."""
+        T, M, N = self.systems.T, self.M, self.num_indv
+        ne, jn = self.num_estimates, self.num_jack
+        name = f"run_{os.path.basename(self.pheno_file) if self.pheno_file is not None else None}"
+        prefix = os.path.join(self.trace_dir, name) if (self.trace_dir and os.path.isdir(self.trace_dir)) else name
+        with open(prefix + ".MN", "w") as fd:
+            fd.write("NSAMPLE,NSNPS,NBLKS,NBINS,K\n")
+            fd.write(f"{N:.0f},{self.num_snp:.0f},{jn:.0f},{self.num_bin:.0f},{self.num_random_vec:.0f}")
+        with open(prefix + ".tr", "w") as fd:
+            fd.write(",".join(f"LD_SUM_{i:d}" for i in range(self.num_bin)) + ",NSNPS_JACKKNIFE\n")
+            for j in range(jn + 1):
+                for a in range(self.num_bin):
+                    vals = []
+                    for b in range(self.num_bin):
+                        mm = M[j, a] * M[j, b]
+                        vals.append((T[j][a, b] - N) * mm / pow(N, 2) if mm != 0 else 0)
+                    fd.write(",".join(f"{v:.3f}" for v in vals) + f",{M[j, a]:.0f}\n")
+        self.log._log(f"Saved trace summary into {prefix}(.tr/.MN)")
 
     def estimate_error(self, ests):
         return est.jackknife_se(ests, self.num_jack)

@@ -115,3 +115,32 @@ def test_genie_matches_reference(name, tmp_path):
     got_lines = "".join(log.msgs[n0:]).splitlines()
     strip = lambda ls: [re.sub(r"-?\d+\.\d+(e-?\d+)?|nan", "#", l) for l in ls]
     assert strip(got_lines) == strip(ref_lines)
+
+
+def test_cli_end_to_end(tmp_path):
+    """run_rhe.py with an ini config in the reference's format -> log file with the reference's grammar."""
+    import subprocess
+    import sys
+    z = load_golden("rhe_3bin_cov")
+    c = fixtures.cohort_from_npz(z)
+    paths = fixtures.write_cohort_files(c, str(tmp_path))
+    out = tmp_path / "out.txt"
+    ini = tmp_path / "cfg.txt"
+    ini.write_text("[PyRHE_Config]\n"
+                   f"genotype = {paths['geno']}\nphenotype = {paths['pheno']}\nannotation={paths['annot']}\n"
+                   f"covariate={paths['cov']}\noutput={out}\nnum_vec = 10\nnum_block = 10\nstreaming = no\nseed = 2\n"
+                   "geno_impute_method = binary\ncov_impute_method = ignore\ndebug = no\n")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "run_rhe.py"), "--config", str(ini), "--suppress"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    # the reference's integration tests parse exactly these patterns (pyrhe/test/integration_test/test_rhe.py:88-145)
+    sig = re.findall(r"Sigma\^2_g\[(\d+)\] : ([-\d.e]+)  SE : ([-\d.e]+)", text)
+    assert len(sig) == 3
+    ref = z["ref_t0_res_sigma_ests_total"]
+    for i, v, _ in sig:
+        assert abs(float(v) - ref[int(i)]) <= 1e-5 * abs(ref[int(i)])
+    assert re.search(r"Sigma\^2_e : ([-\d.e]+)  SE : ([-\d.e]+)", text)
+    assert re.search(r"Total h2 : ([-\d.e]+) SE: ([-\d.e]+)", text)
+    assert "PyRHE (v1.0.0)" in text and re.search(r"Runtime:  [\d.]+", text)
