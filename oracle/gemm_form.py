@@ -46,7 +46,7 @@ def snp_stats(G: np.ndarray, n_indv: int):
     return mu, d
 
 
-def sketch_gemm_form(G: np.ndarray, R: np.ndarray, n_out: int, mode: str = "f16"):
+def sketch_gemm_form(G: np.ndarray, R: np.ndarray, n_out: int, mode: str = "f16", mode2: str = None):
     """G [m, N] ints (missing already filled), R [N, B] float64 right-hand columns.
 
     Returns (V [m, B] float32 = X^T R,  A [N, n_out] float32 = X V[:, :n_out]).
@@ -67,7 +67,7 @@ def sketch_gemm_form(G: np.ndarray, R: np.ndarray, n_out: int, mode: str = "f16"
     # ---- GEMM 2: A = G W - 1 (mu^T W), W = D V
     W = d[:, None] * V[:, :n_out]
     sW = pow2_scale(np.abs(W).max(axis=0), 8192.0)
-    wparts = split_f16(W * sW.astype(np.float32), mode)
+    wparts = split_f16(W * sW.astype(np.float32), mode2 or mode)
     A = np.zeros((N, n_out), np.float32)
     corr = np.zeros(n_out, np.float64)
     for part in wparts:

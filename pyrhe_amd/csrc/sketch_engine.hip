@@ -29,6 +29,7 @@
 #include <string.h>
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 
@@ -94,7 +95,11 @@ __device__ __forceinline__ uint32_t unpack(uint32_t x) {
     constexpr uint32_t mask = 0x00030003u << (2 * T);
     if (!EXACT) return x & mask;
     constexpr float sc = T == 0 ? 1.0f : (T == 1 ? 0.25f : (T == 2 ? 0.0625f : 0.015625f));
-    const uint32_t m = (x & mask) | 0x64006400u;
+    // one v_and_or_b32 (VOP3 takes no literals on gfx9: the mask must sit in a VGPR, the magic in an SGPR; hipcc
+    // otherwise emits v_and + v_or with two literals)
+    uint32_t m;
+    const uint32_t vmask = mask;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(m) : "v"(x), "v"(vmask), "s"(0x64006400u));
     const half2v hx = __builtin_bit_cast(half2v, m);
     const half2v s = {(_Float16)sc, (_Float16)sc};
     const half2v b = {(_Float16)(-1024.0f * sc), (_Float16)(-1024.0f * sc)};
@@ -441,15 +446,17 @@ __global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restr
 // accumulator of MFMA u carries the constant 4^(u&3) * 2^-24, removed once in the epilogue.
 // ------------------------------------------------------------------------------------------------
 template <int NTO, int PARTS, int IW, bool EXACT, bool MISSING>
-__global__ __launch_bounds__(256) void gemm2_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                     const int32_t* __restrict__ rows32, int n_kb,
                                                     int kb_per_split, const float* __restrict__ fill,
                                                     const half8* __restrict__ wfrag,
                                                     const double* __restrict__ corr,
                                                     const float* __restrict__ wscale,
                                                     const float* __restrict__ keep, int n_sketch,
-                                                    int64_t n_pad, float* __restrict__ out, int mode) {
-    // mode: 0 store, 1 read-modify-write, 2 atomicAdd
+                                                    int64_t n_pad, float* __restrict__ out, int mode,
+                                                    float* __restrict__ partial) {
+    // mode: 0 store, 1 read-modify-write, 2 atomicAdd.  With `partial` != NULL, K split y > 0 stores its share
+    // into partial[y-1] (summed into `out` by add_partials_kernel) instead of touching `out`.
     constexpr int NU = 16 * IW;                  // MFMAs (= samples per lane) per step
     constexpr int NS = 3;                        // register ring depth
     extern __shared__ __attribute__((aligned(16))) int32_t s_rows[];
@@ -576,6 +583,10 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const uint8_t* __restrict__ 
             const float cr = blockIdx.y == 0 ? (float)corr[c] : 0.f;
             const float inv = 1.0f / wscale[c];
             float* dst = out + (int64_t)c * n_pad + i0;
+            if (partial && blockIdx.y > 0) {
+                dst = partial + ((int64_t)(blockIdx.y - 1) * n_sketch + c) * n_pad + i0;
+                mode = 0;
+            }
 #pragma unroll
             for (int u4 = 0; u4 < NU / 4; ++u4) {
                 float4 val;
@@ -714,6 +725,8 @@ struct pyrhe_engine {
     float* wscale = nullptr;
     half8* wfrag = nullptr;
     int32_t* rows32 = nullptr;
+    float* partial = nullptr;     // [max 3][n_sketch<=32][n_pad] K-split partial sketches (allocated on first use)
+    size_t partial_bytes = 0;
     // profiling
     bool profile = false;
     struct Ev { int kind; hipEvent_t a, b; };
@@ -804,7 +817,7 @@ extern "C" int pyrhe_engine_destroy(pyrhe_engine_t* e) {
     hipSetDevice(e->device);
     for (auto& ev : e->pool) (void)hipEventDestroy(ev);
     hipFree(e->rfrag); hipFree(e->rscale); hipFree(e->csum); hipFree(e->colmax);
-    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->ws);
+    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->ws); hipFree(e->partial);
     delete e;
     return PYRHE_OK;
 }
@@ -905,12 +918,25 @@ static void launch_gemm1(pyrhe_engine* e, const uint8_t* packed, const int32_t* 
 
 template <int NTO, int PARTS, int IW, bool EXACT>
 static void launch_gemm2(pyrhe_engine* e, const uint8_t* packed, int n_kb, int kbps, int splits, const float* fill,
-                         float* out, int mode, hipStream_t stream) {
+                         float* out, int mode, float* partial, hipStream_t stream) {
     dim3 grid((unsigned)((e->n_pad + 1024 * IW - 1) / (1024 * IW)), splits);
     if (fill)
-        gemm2_kernel<NTO, PARTS, IW, EXACT, true><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode);
+        gemm2_kernel<NTO, PARTS, IW, EXACT, true><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial);
     else
-        gemm2_kernel<NTO, PARTS, IW, EXACT, false><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode);
+        gemm2_kernel<NTO, PARTS, IW, EXACT, false><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial);
+}
+
+// out[i] += sum_s partial[s][i]   (K-split partial sketches; float4 granularity)
+__global__ void add_partials_kernel(float4* __restrict__ out, const float4* __restrict__ partial, int n_parts,
+                                    int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 o = out[i];
+        for (int s = 0; s < n_parts; ++s) {
+            const float4 p = partial[(int64_t)s * n4 + i];
+            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        out[i] = o;
+    }
 }
 
 __global__ void add_norm_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, int accumulate) {
@@ -994,23 +1020,40 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
             if (e->n_sketch) {
                 // 512 samples per wave (8-byte loads, 128 B per row per 16 lanes) when the accumulators fit and the
                 // grid still fills the chip; otherwise 256 samples per wave
-                const int iw = (e->nto == 1 && e->n_pad >= 2048 * 160) ? 2 : 1;
+                // the grid must give every SIMD >= 2 waves (one wave issues a VALU op only every 4 cycles, two
+                // interleave at 2): 512-sample waves only when that still leaves >= 512 workgroups
+                // (measured at N=500k: one fp16 pass is faster with 512-sample waves even at 1 wave/SIMD, the hi+lo
+                // mode with 256-sample waves at 2 waves/SIMD)
+                int iw = (e->nto == 1 && e->parts == 1 && e->n_pad >= 2048 * 160) ? 2 : 1;
+                if (const char* ev = getenv("PYRHE_G2_IW")) iw = atoi(ev) == 2 && e->nto == 1 ? 2 : 1;
                 const int gx = (int)((e->n_pad + 1024 * iw - 1) / (1024 * iw));
                 int splits = gx >= 192 ? 1 : (512 + gx - 1) / gx;
+                if (const char* ev = getenv("PYRHE_G2_SPLITS")) splits = atoi(ev);
                 splits = std::max(splits, (n_kb + 511) / 512);        // row list of a K range lives in LDS: <= 64 KiB
                 splits = std::max(1, std::min(splits, n_kb));
                 const int kbps = (n_kb + splits - 1) / splits;
                 splits = (n_kb + kbps - 1) / kbps;
                 int mode;
                 const bool acc_now = accumulate || !first;
-                if (splits > 1) {
+                float* partial = nullptr;
+                if (splits > 1 && splits <= 4 && sk_stride * (int64_t)sizeof(float) >= (8ll << 20)) {
+                    // big outputs: K splits write private partials, summed by one streaming kernel (no atomics)
+                    const size_t need = (size_t)(splits - 1) * sk_stride * sizeof(float);
+                    if (e->partial_bytes < need) {
+                        if (e->partial) HIPCHK(hipFree(e->partial));
+                        HIPCHK(hipMalloc(&e->partial, need));
+                        e->partial_bytes = need;
+                    }
+                    partial = e->partial;
+                    mode = acc_now ? 1 : 0;
+                } else if (splits > 1) {
                     if (!acc_now) HIPCHK(hipMemsetAsync(outb, 0, sk_stride * sizeof(float), stream));
                     mode = 2;
                 } else {
                     mode = acc_now ? 1 : 0;
                 }
                 ProfScope ps(e, stream, 2);
-#define G2(NTO_, PARTS_, IW_, EX_) launch_gemm2<NTO_, PARTS_, IW_, EX_>(e, packed, n_kb, kbps, splits, fill, outb, mode, stream)
+#define G2(NTO_, PARTS_, IW_, EX_) launch_gemm2<NTO_, PARTS_, IW_, EX_>(e, packed, n_kb, kbps, splits, fill, outb, mode, partial, stream)
                 if (e->parts == 2) {
                     if (iw == 2) G2(1, 2, 2, true); else if (e->nto == 1) G2(1, 2, 1, true); else G2(2, 2, 1, true);
                 } else if (e->exact) {
@@ -1019,6 +1062,10 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                     if (iw == 2) G2(1, 1, 2, false); else if (e->nto == 1) G2(1, 1, 1, false); else G2(2, 1, 1, false);
                 }
 #undef G2
+                if (partial) {
+                    const int64_t n4 = sk_stride / 4;
+                    add_partials_kernel<<<2048, 256, 0, stream>>>((float4*)outb, (const float4*)partial, splits - 1, n4);
+                }
             }
             first = false;
         }
