@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--n-snp", type=int, default=1_000_000)
     ap.add_argument("--jn", type=int, default=100)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--n-bin", type=int, default=1, help="annotation bins (bin(s) = hash(s) mod n_bin; BASELINE configs[3] uses 8)")
+    ap.add_argument("--n-cov", type=int, default=0, help="covariate columns incl. intercept (configs[3]: 11)")
     ap.add_argument("--precision", default=os.environ.get("PYRHE_PRECISION", "f16"), choices=["f16", "f16x2", "f16e"])
     ap.add_argument("--sub-snps", type=int, default=int(os.environ.get("PYRHE_SUB_SNPS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,7 +94,12 @@ def main():
     from pyrhe_amd import estimate as est
 
     N, M, jn, k = args.n_indv, args.n_snp, args.jn, args.k
-    plan = BlockPlan(np.ones((M, 1), np.int8), jn)
+    annot = np.ones((M, 1), np.int8)
+    if args.n_bin > 1:
+        h = (np.arange(M, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)
+        annot = np.zeros((M, args.n_bin), np.int8)
+        annot[np.arange(M), (h % np.uint64(args.n_bin)).astype(np.int64)] = 1
+    plan = BlockPlan(annot, jn)
     j0, j1 = shard_ranges(jn, world)[rank]
     r0 = plan.range(j0)[0] if j1 > j0 else 0
     r1 = plan.range(j1 - 1)[1] if j1 > j0 else 0
@@ -116,7 +123,11 @@ def main():
         g = (g - g.mean()) / g.std()
         y = np.sqrt(args.h2) * g + np.sqrt(1 - args.h2) * y / y.std()
         y -= y.mean()
-    runner = SketchRunner(engine, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, seed=0, streaming=True)
+    cov = None
+    if args.n_cov > 0:
+        cov = np.concatenate([np.ones((N, 1)), np.random.default_rng(2).normal(size=(N, args.n_cov - 1))], axis=1)
+    runner = SketchRunner(engine, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True,
+                          compat="fixed" if cov is not None else "reference")
     runner.begin_trait(y, check_missing=False)      # the generator emits no missing calls (contract of synth_kernel)
 
     def barrier():
@@ -161,7 +172,8 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f16x2" if args.precision == "f16x2" else "f16", "data": "synthetic",
-           "config": {"workload": f"synthetic N={N} M={M} single-bin StreamingRHE sketch pass, k={k} jn={jn}",
+           "config": {"workload": f"synthetic N={N} M={M} {args.n_bin}-bin StreamingRHE sketch pass, k={k} jn={jn}"
+                                  + (f", {args.n_cov} covariates" if args.n_cov else ""),
                       "precision": args.precision, "sub_snps": engine.sub_snps, "parallelism": f"blocks/{world}gpu",
                       "gen_seconds": round(t_gen, 2)},
            "roofline": roofline}

@@ -1027,7 +1027,7 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                 int iw = (e->nto == 1 && e->parts == 1 && e->n_pad >= 2048 * 160) ? 2 : 1;
                 if (const char* ev = getenv("PYRHE_G2_IW")) iw = atoi(ev) == 2 && e->nto == 1 ? 2 : 1;
                 const int gx = (int)((e->n_pad + 1024 * iw - 1) / (1024 * iw));
-                int splits = gx >= 192 ? 1 : (512 + gx - 1) / gx;
+                int splits = gx >= 192 ? 1 : std::min(16, (512 + gx - 1) / gx);
                 if (const char* ev = getenv("PYRHE_G2_SPLITS")) splits = atoi(ev);
                 splits = std::max(splits, (n_kb + 511) / 512);        // row list of a K range lives in LDS: <= 64 KiB
                 splits = std::max(1, std::min(splits, n_kb));
@@ -1036,7 +1036,7 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                 int mode;
                 const bool acc_now = accumulate || !first;
                 float* partial = nullptr;
-                if (splits > 1 && splits <= 4 && sk_stride * (int64_t)sizeof(float) >= (8ll << 20)) {
+                if (splits > 1 && splits <= 16) {
                     // big outputs: K splits write private partials, summed by one streaming kernel (no atomics)
                     const size_t need = (size_t)(splits - 1) * sk_stride * sizeof(float);
                     if (e->partial_bytes < need) {

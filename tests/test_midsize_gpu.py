@@ -1,0 +1,91 @@
+"""Mid-size GPU parity against the reference-order oracle (run live on the box's CPU, no /root/reference needed) on a
+cohort from the device generator, plus size-independent properties at the bench's sample count.
+
+Tolerances:  f16x2: sigma^2 / SE within 1e-5 relative of the oracle (the north-star bound).
+             f16  : sigma^2 within 5e-5 at N = 20 000 (error ~ 2^-12 / sqrt(N k)).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import plink, synth
+from oracle import rhe_oracle as O
+
+pytestmark = pytest.mark.gpu
+SEED = 20251212
+
+
+def _cohort(n, m, dev):
+    from pyrhe_amd import engine
+    geno = engine.synth_genotypes(m, n, SEED, 0, dev)
+    g = synth.synth_rows(SEED, 0, m, n)                      # CPU twin, verified equal in test_engine_gpu
+    rng = np.random.default_rng(3)
+    mu = g.mean(axis=1, keepdims=True)
+    X = ((g - mu) / np.sqrt(mu * (1 - mu / 2))).T
+    beta = rng.normal(0, np.sqrt(0.4 / m), m)
+    y = X @ beta + rng.normal(0, np.sqrt(0.6), n)
+    y -= y.mean()
+    return geno, plink.encode_bed_rows(g), y
+
+
+def _solve(runner, y, jn):
+    from pyrhe_amd import estimate as est
+    sysm = runner.run_trait(y, check_missing=False)
+    sig = np.array([est.solve_normal_equations(sysm.T[j], sysm.q[j].reshape(-1, 1)) for j in range(jn + 1)])
+    return sig[-1], np.array(est.jackknife_se(sig[:-1], jn))
+
+
+@pytest.mark.parametrize("precision,tol", [("f16x2", 1e-5), ("f16", 5e-5)])
+def test_midsize_vs_oracle(precision, tol):
+    from pyrhe_amd import engine
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner
+    dev = torch.device("cuda", 0)
+    n, m, jn, k, nbin = 20000, 2000, 10, 10, 2
+    geno, packed, y = _cohort(n, m, dev)
+    annot = np.zeros((m, nbin), np.int64)
+    annot[np.arange(m), np.arange(m) % nbin] = 1
+    p = O.Problem(packed=packed, n_indv_orig=n, annot=annot, pheno=y.reshape(-1, 1), n_jack=jn, k=k, seed=0)
+    p.Z = O.make_probe_vectors(0, n, k)
+    ref = O.rhe_results(p, O.precompute(p))
+    plan = BlockPlan(annot, jn)
+    eng = engine.SketchEngine(n, n, plan.max_block, precision=precision, device=dev)
+    runner = SketchRunner(eng, geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=p.Z, seed=0, streaming=False)
+    sig, se = _solve(runner, y, jn)
+    assert np.all(np.abs(sig - ref["sigma_ests_total"]) <= tol * np.abs(ref["sigma_ests_total"])), (sig, ref["sigma_ests_total"])
+    assert np.all(np.abs(se - ref["sig_errs"]) <= 10 * tol * np.abs(ref["sig_errs"]))
+    eng.close()
+
+
+def test_linearity_and_block_additivity_at_bench_sample_count():
+    """Size-independent properties at N = 500 000: the sketch is linear in the right-hand columns and additive over
+    SNPs; exact integer genotype sums equal the popcount statistics kernel."""
+    from pyrhe_amd import engine
+    dev = torch.device("cuda", 0)
+    n, m, k = 500_000, 512, 4
+    geno = engine.synth_genotypes(m, n, SEED, 7, dev)
+    eng = engine.SketchEngine(n, n, m, precision="f16x2", device=dev)
+    keep = eng.keep_vector()
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    Z = torch.zeros((k, eng.n_pad), device=dev)
+    Z[:, :n] = torch.randn((k, n), generator=gen).to(dev)
+    y = torch.zeros((1, eng.n_pad), device=dev)
+    y[0, :n] = torch.randn(n, generator=gen).to(dev)
+    ent = torch.arange(m, dtype=torch.int32, device=dev)
+    eng.set_rhs(Z, y, keep)
+    full, nm, cs = eng.sketch_block(geno, ent, [0, m], want_colsum=True)
+    # additivity over SNPs: two halves as two bins of one call == the whole
+    halves, nmh, _ = eng.sketch_block(geno, ent, [0, m // 2, m])
+    assert torch.allclose(halves.sum(0), full[0], rtol=0, atol=2e-6 * full.abs().max().item())
+    assert torch.allclose(nmh.sum(0), nm[0], rtol=1e-6)      # float32 P, different split/atomic order
+    # linearity: columns (z0 + z1, 2 z2) -> (s0 + s1, 2 s2)
+    Z2 = torch.stack([Z[0] + Z[1], 2 * Z[2]])
+    eng.set_rhs(Z2, y, keep)
+    lin, _, _ = eng.sketch_block(geno, ent, [0, m])
+    scale = full.abs().max().item()
+    assert torch.allclose(lin[0, 0], full[0, 0] + full[0, 1], rtol=0, atol=3e-6 * scale)
+    assert torch.allclose(lin[0, 1], 2 * full[0, 2], rtol=0, atol=3e-6 * scale)
+    # exact sums: MFMA ones-column == popcount kernel
+    s, nmiss = eng.block_stats(geno)
+    assert torch.equal(cs, s) and int(nmiss.sum()) == 0
+    assert not full[:, :, n:].any()                       # padding samples stay exactly zero
+    eng.close()
