@@ -336,10 +336,12 @@ class SketchRunner:
         if self.n_gxe:
             e = self.env_pad
             # elem_mul(X, env) then float32 GEMVs in the reference (streaming_genie.py:39-41): X_e X_e^T z = e.(X X^T (e.z))
-            Ae = (self._group(sk_list, "eZ") * e.to(torch.float32)).to(f64)
+            gz = self._group(sk_list, "eZ")
+            Ae = (gz * e.to(gz.dtype)).to(f64)
             A = torch.cat([A, Ae], dim=0)
             if C is not None:
-                Ce = (self._group(sk_list, "eUZ") * e.to(torch.float32)).to(f64)
+                gu = self._group(sk_list, "eUZ")
+                Ce = (gu * e.to(gu.dtype)).to(f64)
                 C = torch.cat([C, Ce], dim=0)
             pe, ce = self.loc["ey"]
             r = torch.cat([r, nm_list[pe][:, ce]], dim=0)
@@ -366,25 +368,34 @@ class SketchRunner:
         ne_g = plan.n_bin + self.n_gxe
         f64 = torch.float64
         use_cov = self.cov is not None
-        tot_A = torch.zeros((ne_g, k, self.n_pad), dtype=f64, device=dev)
-        tot_C = torch.zeros_like(tot_A) if use_cov else None
-        tot_r = torch.zeros(ne_g, dtype=f64, device=dev)
-        D_tot = torch.zeros_like(tot_A) if use_cov else None
-        wsum = torch.zeros_like(tot_A) if (use_cov and self.world > 1) else None
         q4 = use_cov and self.streaming and self.compat == "reference"
-        for jl_i in range(jl):
-            A, C, r = self._block_estimates([b[jl_i] for b in self.blocks_sk], [b[jl_i] for b in self.blocks_nm])
-            tot_A += A
-            tot_r += r
-            if use_cov:
+        wsum = None
+        if not q4:
+            # Block sums as ONE float64 reduction over the stored per-block sketches (the reference adds the blocks one
+            # by one in float64, base.py:468-471; any order agrees to 1e-16).  U is linear, so the "fixed" UXXz total is
+            # U applied to the total (float32 rounding order differs from per-block application at the 1e-7 level).
+            tot_sk = [b.sum(dim=0, dtype=f64) if jl else torch.zeros(b.shape[1:], dtype=f64, device=dev) for b in self.blocks_sk]
+            tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
+            tot_A, tot_C, tot_r = self._block_estimates(tot_sk, tot_nm)
+            tot_A, tot_r = tot_A.contiguous(), tot_r.clone()
+            tot_C = tot_C.contiguous() if use_cov else None
+            D_tot = self._apply_U(tot_A, f32=True) if use_cov else None
+        else:
+            tot_A = torch.zeros((ne_g, k, self.n_pad), dtype=f64, device=dev)
+            tot_C = torch.zeros_like(tot_A)
+            tot_r = torch.zeros(ne_g, dtype=f64, device=dev)
+            D_tot = torch.zeros_like(tot_A)
+            wsum = torch.zeros_like(tot_A) if self.world > 1 else None
+            for jl_i in range(jl):
+                A, C, r = self._block_estimates([b[jl_i] for b in self.blocks_sk], [b[jl_i] for b in self.blocks_nm])
+                tot_A += A
+                tot_r += r
                 tot_C += C
-                if q4 and self.world == 1:
+                if self.world == 1:
                     # quirk Q4 (streaming_rhe.py:18-21): U applied to the RUNNING sum of XXz, float32
                     D_tot += self._apply_U(tot_A, f32=True)
-                elif q4:
-                    wsum += A * float(jn - (self.j0 + jl_i))
                 else:
-                    D_tot += self._apply_U(A, f32=True)
+                    wsum += A * float(jn - (self.j0 + jl_i))
         if self.world > 1:
             self._allreduce(tot_A)
             self._allreduce(tot_r)
@@ -394,7 +405,7 @@ class SketchRunner:
                     self._allreduce(wsum)
                     D_tot = self._apply_U(wsum, f32=True)
                 else:
-                    self._allreduce(D_tot)
+                    D_tot = self._apply_U(tot_A, f32=True)
         self.tot_A, self.tot_C, self.tot_r, self.D_tot = tot_A, tot_C, tot_r, D_tot
         self.tot_sk = tot_A            # [n_est_g, k, n_pad] float64 (kept under the old name for callers)
 
