@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--n-bin", type=int, default=1, help="annotation bins (bin(s) = hash(s) mod n_bin; BASELINE configs[3] uses 8)")
     ap.add_argument("--n-cov", type=int, default=0, help="covariate columns incl. intercept (configs[3]: 11)")
-    ap.add_argument("--precision", default=os.environ.get("PYRHE_PRECISION", "f16x2"), choices=["f16", "f16x2", "f16e"])
+    ap.add_argument("--precision", default=os.environ.get("PYRHE_PRECISION", "i8x3"), choices=["f16", "f16x2", "f16e", "i8x3"])
     ap.add_argument("--sub-snps", type=int, default=int(os.environ.get("PYRHE_SUB_SNPS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-snps", type=int, default=0, help="SNPs in the CPU baseline sample (0 = auto)")
@@ -172,7 +172,7 @@ def main():
     out = {"metric": "SNPs/sec through streaming trace sketch (N=500k, k=10, jn=100)", "value": value, "unit": "SNPs/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "f16x2" if args.precision == "f16x2" else "f16", "data": "synthetic",
+           "dtype": {"f16x2": "f16x2", "i8x3": "i8x3+f16x2", "f16": "f16", "f16e": "f16"}[args.precision], "data": "synthetic",
            "config": {"workload": f"synthetic N={N} M={M} {args.n_bin}-bin StreamingRHE sketch pass, k={k} jn={jn}"
                                   + (f", {args.n_cov} covariates" if args.n_cov else ""),
                       "precision": args.precision, "sub_snps": engine.sub_snps, "parallelism": f"blocks/{world}gpu",
@@ -185,7 +185,7 @@ def main():
         out["config"]["sigma_total"] = [float(v) for v in sig[-1]]
         out["config"]["sigma_se"] = [float(v) for v in est.jackknife_se(np.array(sig[:-1]), jn)]
 
-    if not args.no_alt and args.precision == "f16x2":
+    if not args.no_alt and args.precision in ("f16x2", "i8x3"):
         # the same pass in the single-rounding mode (1 MFMA per fragment, subnormal unpack): reported beside the
         # headline, never as `value` -- its sigma^2 error is ~2^-12/sqrt(N k), not bounded by 1e-5 at every size
         del runner

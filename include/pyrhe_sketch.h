@@ -46,6 +46,9 @@ extern "C" {
 #define PYRHE_PREC_F16_EXACT 2 /* one fp16 rounding, genotypes unpacked to normal fp16 numbers (3 VALU ops per
                                   register pair instead of the 1-op subnormal unpack of PYRHE_PREC_F16)        */
 
+#define PYRHE_PREC_I8X3 3   /* GEMM 1 on three int8 limbs (22 bits of the column maximum, exact int32 accumulation,
+                               2x K per MFMA); GEMM 2 as PYRHE_PREC_F16X2.  Parity-safe like F16X2, less work.      */
+
 /* column roles for pyrhe_engine_set_rhs */
 #define PYRHE_COL_SKETCH 1  /* gets both contractions: out[:, col] = X (X^T r)   (a7/a9 in SURVEY 8a) */
 #define PYRHE_COL_NORM 2    /* gets sum_s (x_s^T r)^2                            (a8)                 */

@@ -38,6 +38,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef int int4v __attribute__((ext_vector_type(4)));
 
 union Frag {
     half8 h;
@@ -347,9 +348,186 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// int8 variant of GEMM 1 (precision i8x3): R is split into three int8 limbs, x = R * s (|x| <= 127, s a power of
+// two), x ~ a1 + a2/128 + a3/16384 (22 bits relative to the column maximum), genotypes are unpacked to bytes
+// ((v >> 2t) & 0x03030303: 7 VALU ops per 16 genotypes) and multiplied on v_mfma_i32_16x16x64_i8 -- twice the K
+// per instruction of the fp16 form at the same cycles, EXACT int32 accumulation, integer atomics (deterministic).
+// Operand map (tools/probe_i8.hip): lane l holds bytes k = 16 (l>>4) + j of row / column l&15.
+// Byte 4t+b of a lane's fragment = crumb t + 4b of its dword.
+// Rimg layout: [chunk][dword d 4][limb 3][tile][lane 64][16 bytes].
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float i8_scale(float maxabs) {
+    if (!(maxabs > 0.0f) || !isfinite(maxabs)) return 1.0f;
+    int e;
+    frexpf(maxabs, &e);                 // maxabs < 2^e  ->  maxabs * 2^(6-e) < 64 <= 127
+    return ldexpf(1.0f, 6 - e);
+}
+
+__global__ void prep_rimg_i8_kernel(const float* __restrict__ R, const float* __restrict__ keep, int64_t n_pad,
+                                    int n_user_cols, int ntl, const uint32_t* __restrict__ colmax_bits,
+                                    float* __restrict__ scale, int4v* __restrict__ rimg, double* __restrict__ csum) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = gid & 63;
+    int64_t rest = gid >> 6;
+    const int tile = rest % ntl;
+    rest /= ntl;
+    const int limb = rest % 3;
+    rest /= 3;
+    const int d = rest & 3;
+    const int64_t chunk = rest >> 2;
+    if (chunk * 256 >= n_pad) return;
+    const int c = tile * 16 + (lane & 15);
+    const int q = lane >> 4;
+    float s = 1.0f;
+    if (c < n_user_cols) s = i8_scale(__uint_as_float(colmax_bits[c]));
+    uint32_t w[4];
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t i = chunk * 256 + q * 64 + d * 16 + t + 4 * b;
+            float x = 0.0f;
+            if (c < n_user_cols) x = R[(int64_t)c * n_pad + i] * s;
+            else if (c == n_user_cols) x = keep[i];
+            const float a1 = rintf(x);
+            const float r1 = (x - a1) * 128.0f;
+            const float a2 = rintf(r1);
+            const float a3 = rintf((r1 - a2) * 128.0f);
+            const float a = limb == 0 ? a1 : (limb == 1 ? a2 : a3);
+            acc += (double)a * (limb == 0 ? 1.0 : (limb == 1 ? 1.0 / 128.0 : 1.0 / 16384.0));
+            word |= ((uint32_t)(int)a & 0xFFu) << (8 * b);
+        }
+        w[t] = word;
+    }
+    rimg[gid] = (int4v){(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if (q == 0 && c <= n_user_cols) atomicAdd(&csum[c], acc);
+    if (chunk == 0 && d == 0 && limb == 0 && q == 0) scale[c] = s;
+}
+
+template <int NTL, bool MISSING>
+__global__ __launch_bounds__(256) void gemm1_i8_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
+                                                       const int32_t* __restrict__ rows, int n_entries,
+                                                       const float* __restrict__ fill,
+                                                       const int4v* __restrict__ rimg, int n_steps,
+                                                       int steps_per_split, int* __restrict__ P, int use_atomic) {
+    constexpr int CH = 2;                        // 256-sample chunks per step
+    constexpr int FR = 12 * NTL;                 // 1-KiB fragments per chunk: 4 dwords x 3 limbs x NTL
+    constexpr int LD = CH * FR / 4;
+    extern __shared__ __attribute__((aligned(16))) int4v ibuf[];   // [2][CH * FR * 64]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int ebase = (blockIdx.x * 4 + wave) * 64;
+    const int s0 = blockIdx.y * steps_per_split;
+    const int s1 = min(s0 + steps_per_split, n_steps);
+    if (s0 >= s1) return;
+    const uint8_t* rowp[4];
+    int fillv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int e = ebase + 16 * t + r;
+        e = e < n_entries ? e : n_entries - 1;
+        const int row = rows[e];
+        rowp[t] = packed + (int64_t)row * pitch + 16 * q;
+        fillv[t] = MISSING ? (int)fill[row] : 0;
+    }
+    int4v acc[4][3][NTL];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int n = 0; n < NTL; ++n) acc[t][l][n] = (int4v){0, 0, 0, 0};
+    uint4 g[2][4][CH];
+    int4v rs[LD];
+    auto issue_g = [&](int s, uint4 (&gg)[4][CH]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch)
+                gg[t][ch] = *reinterpret_cast<const uint4*>(rowp[t] + (int64_t)s * (64 * CH) + 64 * ch);
+    };
+    auto issue_r = [&](int s) {
+        const int4v* src = rimg + (int64_t)s * (CH * FR * 64) + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < LD; ++i) rs[i] = src[i * 256];
+    };
+    auto stage_r = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LD; ++i) ibuf[buf * (CH * FR * 64) + i * 256 + threadIdx.x] = rs[i];
+    };
+    auto compute = [&](const uint4 (&gg)[4][CH], int buf) {
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            const int4v* rf = ibuf + buf * (CH * FR * 64) + ch * (FR * 64) + lane;
+            int4v b[4][3][NTL];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int l = 0; l < 3; ++l)
+#pragma unroll
+                    for (int n = 0; n < NTL; ++n) b[d][l][n] = rf[((d * 3 + l) * NTL + n) * 64];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t w = d == 0 ? gg[t][ch].x : (d == 1 ? gg[t][ch].y : (d == 2 ? gg[t][ch].z : gg[t][ch].w));
+                    uint32_t v = value_code(w);
+                    if (MISSING) v = apply_fill(v, missing_mask(w), fillv[t]);
+                    const int4v a = {(int)(v & 0x03030303u), (int)((v >> 2) & 0x03030303u),
+                                     (int)((v >> 4) & 0x03030303u), (int)((v >> 6) & 0x03030303u)};
+#pragma unroll
+                    for (int l = 0; l < 3; ++l)
+#pragma unroll
+                        for (int n = 0; n < NTL; ++n)
+                            acc[t][l][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[d][l][n], acc[t][l][n], 0, 0, 0);
+                }
+            }
+        }
+    };
+    issue_g(s0, g[0]);
+    issue_r(s0);
+    stage_r(0);
+    __syncthreads();
+    for (int s = s0; s < s1; s += 2) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int nxt = min(s + k + 1, s1 - 1);
+            issue_r(nxt);
+            issue_g(nxt, g[k ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(g[k], k);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_r(k ^ 1);
+            __syncthreads();
+        }
+    }
+    // P layout: [entry][limb][16 NTL columns] int32
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int n = 0; n < NTL; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int e = ebase + 16 * t + 4 * q + reg;
+                    if (e < n_entries) {
+                        int* dst = P + ((int64_t)e * 3 + l) * (16 * NTL) + n * 16 + r;
+                        if (use_atomic) atomicAdd(dst, acc[t][l][n][reg]);
+                        else *dst = acc[t][l][n][reg];
+                    }
+                }
+}
+
+// ------------------------------------------------------------------------------------------------
 // mid 1: per entry statistics, V = X^T R, norm accumulation, W = D V (float32) + column maxima
 // ------------------------------------------------------------------------------------------------
-__global__ void mid1_kernel(const float* __restrict__ P, float pscale, int n_entries, int ncol_p, int n_sketch, int n_norm,
+__global__ void mid1_kernel(const float* __restrict__ P, float pscale, int i8, int n_entries, int ncol_p, int n_sketch, int n_norm,
                             const float* __restrict__ scale, const double* __restrict__ csum, float n_keep,
                             float* __restrict__ mu_out, float* __restrict__ Wtmp,
                             uint32_t* __restrict__ wmax_bits, double* __restrict__ norm_acc,
@@ -359,7 +537,9 @@ __global__ void mid1_kernel(const float* __restrict__ P, float pscale, int n_ent
     float mu = 0.f, d = 0.f;
     const bool live = e < n_entries;
     if (live) {
-        const float sum = P[(int64_t)e * ncol_p + ones] * pscale;   // exact integer (< 2^24); P carries 1/pscale (2^-24 with the subnormal unpack)
+        // exact integer (< 2^24); float P carries 1/pscale (2^-24 with the subnormal unpack); int8 mode: limb 0 as int32
+        const float sum = i8 ? (float)reinterpret_cast<const int*>(P)[(int64_t)e * 3 * ncol_p + ones]
+                             : P[(int64_t)e * ncol_p + ones] * pscale;
         // float32, the reference's operation order (base.py:292-293): mean; 1/sqrt(mean*(1-0.5*mean))
         mu = sum / n_keep;
         d = 1.0f / sqrtf(mu * (1.0f - 0.5f * mu));
@@ -370,7 +550,13 @@ __global__ void mid1_kernel(const float* __restrict__ P, float pscale, int n_ent
         float v = 0.f;
         if (live) {
             const double inv_s = 1.0 / (double)scale[c];
-            const double pc = (double)P[(int64_t)e * ncol_p + c] * (double)pscale * inv_s;
+            double pc;
+            if (i8) {
+                const int* Pi = reinterpret_cast<const int*>(P) + (int64_t)e * 3 * ncol_p + c;
+                pc = ((double)Pi[0] + (double)Pi[ncol_p] * (1.0 / 128.0) + (double)Pi[2 * ncol_p] * (1.0 / 16384.0)) * inv_s;
+            } else {
+                pc = (double)P[(int64_t)e * ncol_p + c] * (double)pscale * inv_s;
+            }
             v = (float)((double)d * (pc - (double)mu * (csum[c] * inv_s)));
         }
         if (c < n_sketch) {
@@ -703,6 +889,7 @@ struct pyrhe_engine {
     int64_t n_keep = 0, pitch = 0, n_pad = 0, max_entries = 0, sub_snps = 0;
     int precision = 0, parts = 1;
     bool exact = false;   // exact (normal-number) genotype unpack instead of the 1-op subnormal unpack
+    bool i8 = false;      // GEMM 1 on int8 limbs (precision i8x3); GEMM 2 then runs the hi+lo fp16 form
     int n_sketch = 0, n_norm = 0, n_user = 0, ntl = 0, nto = 0;
     bool rhs_set = false;
     // device buffers
@@ -752,7 +939,8 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     if (pitch <= 0 || pitch % 256) return fail(PYRHE_EINVAL, "pitch (%lld) must be a positive multiple of 256", (long long)pitch);
     if (n_keep <= 0 || n_keep > 4 * pitch) return fail(PYRHE_EINVAL, "n_keep (%lld) must be in 1..4*pitch", (long long)n_keep);
     if (n_keep >= (1 << 23)) return fail(PYRHE_EINVAL, "n_keep (%lld) >= 2^23: genotype sums would not be exact in float32", (long long)n_keep);
-    if (precision != PYRHE_PREC_F16 && precision != PYRHE_PREC_F16X2 && precision != PYRHE_PREC_F16_EXACT)
+    if (precision != PYRHE_PREC_F16 && precision != PYRHE_PREC_F16X2 && precision != PYRHE_PREC_F16_EXACT &&
+        precision != PYRHE_PREC_I8X3)
         return fail(PYRHE_EINVAL, "unknown precision %d", precision);
     if (max_entries <= 0) return fail(PYRHE_EINVAL, "max_entries must be positive");
     HIPCHK(hipSetDevice(device));
@@ -762,8 +950,9 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     e->pitch = pitch;
     e->n_pad = 4 * pitch;
     e->precision = precision;
-    e->parts = precision == PYRHE_PREC_F16X2 ? 2 : 1;
+    e->parts = (precision == PYRHE_PREC_F16X2 || precision == PYRHE_PREC_I8X3) ? 2 : 1;
     e->exact = precision != PYRHE_PREC_F16;
+    e->i8 = precision == PYRHE_PREC_I8X3;
     if (sub_snps <= 0) {
         // Whole blocks per kernel pair.  Measured on MI355X (tools/microbench.hip E2): re-reading a sub-block that
         // was just streamed (Infinity Cache) is at most ~20 % faster than HBM, while short launches lose more than
@@ -786,7 +975,7 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     const size_t S = (size_t)sub_snps;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-    const size_t oP = carve(S * ncolmax * sizeof(float));
+    const size_t oP = carve(S * ncolmax * sizeof(float) * (precision == PYRHE_PREC_I8X3 ? 3 : 1));
     const size_t oWmax = carve(ncolmax * sizeof(uint32_t));
     const size_t oCorr = carve(ncolmax * sizeof(double));
     const size_t oNorm = carve(ncolmax * sizeof(double));
@@ -868,7 +1057,11 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
     {
         const int64_t threads = (e->n_pad / 256) * 8 * e->parts * e->ntl * 64;
         const unsigned grid = (unsigned)((threads + 255) / 256);
-        if (e->parts == 2)
+        if (e->i8) {
+            const int64_t th = (e->n_pad / 256) * 4 * 3 * e->ntl * 64;
+            prep_rimg_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale,
+                                                                              (int4v*)e->rfrag, e->csum);
+        } else if (e->parts == 2)
             prep_rfrag_kernel<2, true><<<grid, 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale, e->rfrag, e->csum);
         else if (e->exact)
             prep_rfrag_kernel<1, true><<<grid, 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale, e->rfrag, e->csum);
@@ -997,7 +1190,18 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                 splits = (n_steps + cps - 1) / cps;
                 ProfScope ps(e, stream, 0);
 #define G1(NTL_, PARTS_, EX_) launch_gemm1<NTL_, PARTS_, EX_>(e, packed, rows, n, fill, n_steps, cps, splits, stream)
-                if (e->parts == 2) { if (e->ntl == 1) G1(1, 2, true); else G1(2, 2, true); }
+                if (e->i8) {
+                    dim3 grid((n + 255) / 256, splits);
+                    const size_t lds = (size_t)2 * 2 * 12 * e->ntl * 1024;
+                    const int ua = splits > 1;
+                    if (e->ntl == 1) {
+                        if (fill) gemm1_i8_kernel<1, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)e->P, ua);
+                        else gemm1_i8_kernel<1, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)e->P, ua);
+                    } else {
+                        if (fill) gemm1_i8_kernel<2, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)e->P, ua);
+                        else gemm1_i8_kernel<2, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)e->P, ua);
+                    }
+                } else if (e->parts == 2) { if (e->ntl == 1) G1(1, 2, true); else G1(2, 2, true); }
                 else if (e->exact) { if (e->ntl == 1) G1(1, 1, true); else G1(2, 1, true); }
                 else { if (e->ntl == 1) G1(1, 1, false); else G1(2, 1, false); }
 #undef G1
@@ -1005,7 +1209,7 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
             // ---- mid
             {
                 ProfScope ps(e, stream, 1);
-                mid1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->exact ? 1.0f : 16777216.0f, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
+                mid1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->exact ? 1.0f : 16777216.0f, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
                                                                  (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->normacc,
                                                                  out_colsum ? out_colsum + offsets_host[b] + s0 : nullptr);
                 if (e->n_sketch) {

@@ -18,7 +18,8 @@ from .build import library_path
 PREC_F16 = 0
 PREC_F16X2 = 1
 PREC_F16_EXACT = 2
-PRECISIONS = {"f16": PREC_F16, "f16x2": PREC_F16X2, "f16e": PREC_F16_EXACT}
+PREC_I8X3 = 3
+PRECISIONS = {"f16": PREC_F16, "f16x2": PREC_F16X2, "f16e": PREC_F16_EXACT, "i8x3": PREC_I8X3}
 COL_SKETCH = 1
 COL_NORM = 2
 ROW_ALIGN = 256           # pitch granularity (bytes)
@@ -137,7 +138,7 @@ class SketchEngine:
     """One engine per GPU.  Mirrors what ``Base._compute_XXz/_XXUz/_yXXy`` + ``standardize_geno`` +
     ``read_geno`` do for a block (reference ``pyrhe/src/base/base.py:291-296,338-356,403-417``)."""
 
-    def __init__(self, n_samples_orig: int, n_keep: int, max_entries: int, precision: str = "f16x2",
+    def __init__(self, n_samples_orig: int, n_keep: int, max_entries: int, precision: str = "i8x3",
                  device="cuda", sub_snps: int = 0):
         self.device = _require_gpu(device)
         self.lib = load_library()

@@ -38,7 +38,7 @@ class Base:
                  device: str = "cuda", cuda_num: Optional[int] = None, num_workers: Optional[int] = None,
                  multiprocessing: bool = True, seed: Optional[int] = None, get_trace: bool = False,
                  trace_dir: Optional[str] = None, samp_prev: Optional[float] = None, pop_prev: Optional[float] = None,
-                 log: Optional[Logger] = None, precision: str = "f16x2", compat: str = "reference",
+                 log: Optional[Logger] = None, precision: str = "i8x3", compat: str = "reference",
                  recompute_pass2: bool = False, sub_snps: int = 0):
         self.model = model
         self.num_jack = self.num_blocks = int(num_jack)

@@ -4,6 +4,7 @@ Tolerances (written here, as the task requires):
   * decode, genotype sums, block indexing: bit-exact.
   * per-block sketches X(X^T z), ||X^T y||^2 vs the reference's float32 GEMV results:
       f16x2 mode: 5e-6 of the block's max |value|   (fp32 accumulation-order noise only)
+      i8x3  mode: 5e-6 (int8-limb GEMM 1 with exact integer accumulation + hi/lo fp16 GEMM 2)
       f16   mode: 2e-3 of the block's max |value|   (one fp16 rounding of Z and of W = D V)
 """
 import numpy as np
@@ -16,7 +17,7 @@ from tests.helpers import load_golden, oracle_problem
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"f16x2": 5e-6, "f16": 2e-3}
+TOL = {"f16x2": 5e-6, "f16": 2e-3, "i8x3": 5e-6}
 
 
 @pytest.fixture(scope="module")
@@ -84,7 +85,7 @@ def _engine_block_sketches(p, c, dev, precision, fill_by_block=None):
     return XXz, yXXy, colsums
 
 
-@pytest.mark.parametrize("precision", ["f16x2", "f16"])
+@pytest.mark.parametrize("precision", ["f16x2", "f16", "i8x3"])
 @pytest.mark.parametrize("name", ["rhe_1bin_nocov", "rhe_3bin_nocov_rem", "rhe_1bin_n1024"])
 def test_block_sketch_vs_reference_golden(dev, name, precision):
     z = load_golden(name)

@@ -35,7 +35,7 @@ def _solve(runner, y, jn):
     return sig[-1], np.array(est.jackknife_se(sig[:-1], jn))
 
 
-@pytest.mark.parametrize("precision,tol", [("f16x2", 1e-5), ("f16", 5e-5)])
+@pytest.mark.parametrize("precision,tol", [("f16x2", 1e-5), ("i8x3", 1e-5), ("f16", 5e-5)])
 def test_midsize_vs_oracle(precision, tol):
     from pyrhe_amd import engine
     from pyrhe_amd.streaming import BlockPlan, SketchRunner

@@ -80,6 +80,14 @@ def test_recompute_pass2_equals_stored_blocks(tmp_path):
     assert np.allclose(ra["sig_errs"], rb["sig_errs"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("name", ["rhe_3bin_cov", "rhe_1bin_missing", "rhe_1bin_n1024"])
+def test_i8x3_mode_matches_reference(name, tmp_path):
+    """int8-limb GEMM 1 (two column tiles with covariates, missing-call fill path): same 1e-5 bound as f16x2."""
+    z = load_golden(name)
+    m, _ = _run_model(z, tmp_path, "RHE", precision="i8x3")
+    _assert_dict(m(trait=0), z, 0, RESULT_KEYS_RHE)
+
+
 def test_f16_mode_close(tmp_path):
     """Single-rounding mode: documented looser bound on the tiny fixtures (error ~ 2^-12 / sqrt(N k))."""
     z = load_golden("rhe_1bin_n1024")
