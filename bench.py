@@ -162,8 +162,20 @@ def main():
     dom_ms = max(g1, g2)
     bytes_per_launch = local_snps * row_bytes / launches                    # algorithmic bytes: ceil(N/4) per SNP
     achieved = bytes_per_launch / (dom_ms / launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md), only
+    # when this run has the shape those passes were taken on (whole 10 000-SNP blocks at N = 500 000)
+    traffic = None
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as fh:
+            tj = json.load(fh)
+        key = {"gemm1_kernel": "gemm1_i8_kernel" if args.precision == "i8x3" else "gemm1_kernel_f16",
+               "gemm2_kernel": "gemm2_kernel_f16" if args.precision == "f16" else "gemm2_kernel_f16x2"}[dom]
+        if N == tj["n_indv"] and M // jn == tj["block_snps"] and args.n_bin == 1:
+            traffic = tj["kernels"][key]["bytes"]
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(dom_ms / launches, 4),
                 "gemm1_ms_per_step": round(g1 / args.steps, 3), "gemm2_ms_per_step": round(g2 / args.steps, 3),
                 "mid_ms_per_step": round(prof["mid_ms"] / args.steps, 3),

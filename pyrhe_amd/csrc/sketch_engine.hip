@@ -708,25 +708,27 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const uint8_t* __restrict
                 x[p] = __builtin_amdgcn_perm(v[2 * p + 1], v[2 * p], 0x05040100u);
                 y[p] = __builtin_amdgcn_perm(v[2 * p + 1], v[2 * p], 0x07060302u);
             }
+            // fragments in groups of 4 (crumbs 0..3 of one source register set): unpack all four, then issue their MFMAs
+            // round-robin so consecutive matrix instructions never touch the same accumulator or operand registers
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                Frag f;
+            for (int ug = 0; ug < 4; ++ug) {
+                Frag f[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    uint32_t src = (u & 8) ? y[p] : x[p];
-                    if (u & 4) src >>= 8;
-                    switch (u & 3) {
-                        case 0: f.u[p] = unpack<0, EXACT>(src); break;
-                        case 1: f.u[p] = unpack<1, EXACT>(src); break;
-                        case 2: f.u[p] = unpack<2, EXACT>(src); break;
-                        default: f.u[p] = unpack<3, EXACT>(src); break;
-                    }
+                    uint32_t src = (ug & 2) ? y[p] : x[p];
+                    if (ug & 1) src >>= 8;
+                    f[0].u[p] = unpack<0, EXACT>(src);
+                    f[1].u[p] = unpack<1, EXACT>(src);
+                    f[2].u[p] = unpack<2, EXACT>(src);
+                    f[3].u[p] = unpack<3, EXACT>(src);
                 }
 #pragma unroll
                 for (int p = 0; p < PARTS; ++p)
 #pragma unroll
                     for (int t = 0; t < NTO; ++t)
-                        acc[t][iw * 16 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aa[p][t], f.h, acc[t][iw * 16 + u], 0, 0, 0);
+#pragma unroll
+                        for (int uu = 0; uu < 4; ++uu)
+                            acc[t][iw * 16 + ug * 4 + uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aa[p][t], f[uu].h, acc[t][iw * 16 + ug * 4 + uu], 0, 0, 0);
             }
         }
     };
