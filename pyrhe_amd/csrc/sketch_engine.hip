@@ -916,6 +916,23 @@ struct pyrhe_engine {
     int32_t* rows32 = nullptr;
     float* partial = nullptr;     // [max 3][n_sketch<=32][n_pad] K-split partial sketches (allocated on first use)
     size_t partial_bytes = 0;
+    // Two workspace sets + two internal streams: GEMM 1 (+ mid) of sub-block g+1 runs on stream A while GEMM 2 of
+    // sub-block g runs on stream B -- a DRAM-pattern-bound kernel beside an instruction-bound one.  The members
+    // above alias the set in use (kernel arguments are captured by value at launch).
+    struct WorkSet {
+        uint8_t* base; float* P; uint32_t* wmax; double* corr; double* normacc; float* mu; float* Wtmp; float* wscale;
+        half8* wfrag; int32_t* rows32;
+    } sets[2];
+    hipStream_t sA = nullptr, sB = nullptr;
+    hipEvent_t evIn = nullptr, evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, evDoneA = nullptr, evDoneB = nullptr;
+    uint64_t sub_counter = 0;     // sub-blocks enqueued so far (set = counter & 1)
+    bool async_join = false;      // true: the caller joins with pyrhe_engine_join instead of at the end of every call
+    bool pending = false;         // work enqueued on the internal streams that the caller's stream has not joined yet
+    void use_set(int i) {
+        const WorkSet& w = sets[i];
+        ws = w.base; P = w.P; wmax = w.wmax; corr = w.corr; normacc = w.normacc; mu = w.mu; Wtmp = w.Wtmp;
+        wscale = w.wscale; wfrag = w.wfrag; rows32 = w.rows32;
+    }
     // profiling
     bool profile = false;
     struct Ev { int kind; hipEvent_t a, b; };
@@ -988,17 +1005,31 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     const size_t oWfrag = carve((S / 32) * e->parts * kMaxTiles * 64 * sizeof(half8));
     const size_t oRows = carve(S * sizeof(int32_t));
     e->ws_bytes = off;
-    HIPCHK(hipMalloc(&e->ws, e->ws_bytes));
-    e->P = (float*)(e->ws + oP);
-    e->wmax = (uint32_t*)(e->ws + oWmax);
-    e->corr = (double*)(e->ws + oCorr);
-    e->normacc = (double*)(e->ws + oNorm);
-    e->mu = (float*)(e->ws + oMu);
-    e->Wtmp = (float*)(e->ws + oWtmp);
-    e->wscale = (float*)(e->ws + oWscale);
-    e->wfrag = (half8*)(e->ws + oWfrag);
-    e->rows32 = (int32_t*)(e->ws + oRows);
-    e->total_bytes = e->ws_bytes + e->rfrag_bytes + e->n_pad * 4 + e->n_pad / 4;
+    for (int i = 0; i < 2; ++i) {
+        uint8_t* base = nullptr;
+        HIPCHK(hipMalloc(&base, e->ws_bytes));
+        HIPCHK(hipMemset(base, 0, e->ws_bytes));
+        pyrhe_engine::WorkSet& w = e->sets[i];
+        w.base = base;
+        w.P = (float*)(base + oP);
+        w.wmax = (uint32_t*)(base + oWmax);
+        w.corr = (double*)(base + oCorr);
+        w.normacc = (double*)(base + oNorm);
+        w.mu = (float*)(base + oMu);
+        w.Wtmp = (float*)(base + oWtmp);
+        w.wscale = (float*)(base + oWscale);
+        w.wfrag = (half8*)(base + oWfrag);
+        w.rows32 = (int32_t*)(base + oRows);
+        HIPCHK(hipEventCreateWithFlags(&e->evA[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->evB[i], hipEventDisableTiming));
+    }
+    e->use_set(0);
+    HIPCHK(hipStreamCreateWithFlags(&e->sA, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->sB, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->evIn, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evDoneA, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evDoneB, hipEventDisableTiming));
+    e->total_bytes = 2 * e->ws_bytes + e->rfrag_bytes + e->n_pad * 4 + e->n_pad / 4;
     *out = e;
     return PYRHE_OK;
 }
@@ -1008,7 +1039,17 @@ extern "C" int pyrhe_engine_destroy(pyrhe_engine_t* e) {
     hipSetDevice(e->device);
     for (auto& ev : e->pool) (void)hipEventDestroy(ev);
     hipFree(e->rfrag); hipFree(e->rscale); hipFree(e->csum); hipFree(e->colmax);
-    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->ws); hipFree(e->partial);
+    if (e->sA) { (void)hipStreamSynchronize(e->sA); (void)hipStreamDestroy(e->sA); }
+    if (e->sB) { (void)hipStreamSynchronize(e->sB); (void)hipStreamDestroy(e->sB); }
+    for (int i = 0; i < 2; ++i) {
+        if (e->evA[i]) (void)hipEventDestroy(e->evA[i]);
+        if (e->evB[i]) (void)hipEventDestroy(e->evB[i]);
+        hipFree(e->sets[i].base);
+    }
+    if (e->evIn) (void)hipEventDestroy(e->evIn);
+    if (e->evDoneA) (void)hipEventDestroy(e->evDoneA);
+    if (e->evDoneB) (void)hipEventDestroy(e->evDoneB);
+    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->partial);
     delete e;
     return PYRHE_OK;
 }
@@ -1043,6 +1084,10 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
     }
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(e->device));
+    if (e->pending) {      // earlier sketches on the internal streams still read the old operand image
+        HIPCHK(hipStreamWaitEvent(stream, e->evDoneA, 0));
+        HIPCHK(hipStreamWaitEvent(stream, e->evDoneB, 0));
+    }
     e->n_sketch = ns;
     e->n_norm = nn;
     e->n_user = n_cols;
@@ -1156,8 +1201,13 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                         (long long)(offsets_host[b + 1] - offsets_host[b]), (long long)e->max_entries);
     }
     if (offsets_host[nbin] > 0 && !entries) return fail(PYRHE_EINVAL, "entries is NULL");
-    hipStream_t stream = (hipStream_t)stream_;
+    hipStream_t caller = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(e->device));
+    // inputs (and the output buffers) are ready on the caller's stream at this point of ITS order
+    HIPCHK(hipEventRecord(e->evIn, caller));
+    HIPCHK(hipStreamWaitEvent(e->sA, e->evIn, 0));
+    HIPCHK(hipStreamWaitEvent(e->sB, e->evIn, 0));
+    hipStream_t stream = e->sA;      // GEMM 1 + mid kernels; GEMM 2 goes to e->sB below
     const int n_chunks = (int)(e->pitch / 64);
     const int ncol_p = 16 * e->ntl;
     const int64_t sk_stride = (int64_t)e->n_sketch * e->n_pad;
@@ -1168,7 +1218,7 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
         double* normb = out_norm ? out_norm + (int64_t)b * e->n_norm : nullptr;
         if (n_b == 0) {
             if (!accumulate) {
-                if (outb) HIPCHK(hipMemsetAsync(outb, 0, sk_stride * sizeof(float), stream));
+                if (outb) HIPCHK(hipMemsetAsync(outb, 0, sk_stride * sizeof(float), e->sB));
                 if (normb && e->n_norm) HIPCHK(hipMemsetAsync(normb, 0, e->n_norm * sizeof(double), stream));
             }
             continue;
@@ -1179,6 +1229,10 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
             const int32_t* rows = entries + offsets_host[b] + s0;
             const int n32 = (n + 31) / 32 * 32;
             const int n_kb = n32 / 32;
+            const int set = (int)(e->sub_counter & 1);
+            e->use_set(set);
+            if (e->sub_counter >= 2) HIPCHK(hipStreamWaitEvent(e->sA, e->evB[set], 0));   // GEMM 2 of sub-block g-2 is done with this set
+            e->sub_counter++;
             HIPCHK(hipMemsetAsync(e->ws, 0, e->zero_bytes, stream));
             pad_rows_kernel<<<(n32 + 255) / 256, 256, 0, stream>>>(rows, n, n32, e->rows32);
             // ---- GEMM 1
@@ -1222,7 +1276,9 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                 }
                 if (e->n_norm) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc, normb, e->n_norm, accumulate || !first);
             }
-            // ---- GEMM 2
+            // ---- GEMM 2 on stream B, behind this sub-block's mid kernels
+            HIPCHK(hipEventRecord(e->evA[set], e->sA));
+            HIPCHK(hipStreamWaitEvent(e->sB, e->evA[set], 0));
             if (e->n_sketch) {
                 // 512 samples per wave (8-byte loads, 128 B per row per 16 lanes) when the accumulators fit and the
                 // grid still fills the chip; otherwise 256 samples per wave
@@ -1253,13 +1309,13 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                     partial = e->partial;
                     mode = acc_now ? 1 : 0;
                 } else if (splits > 1) {
-                    if (!acc_now) HIPCHK(hipMemsetAsync(outb, 0, sk_stride * sizeof(float), stream));
+                    if (!acc_now) HIPCHK(hipMemsetAsync(outb, 0, sk_stride * sizeof(float), e->sB));
                     mode = 2;
                 } else {
                     mode = acc_now ? 1 : 0;
                 }
-                ProfScope ps(e, stream, 2);
-#define G2(NTO_, PARTS_, IW_, EX_) launch_gemm2<NTO_, PARTS_, IW_, EX_>(e, packed, n_kb, kbps, splits, fill, outb, mode, partial, stream)
+                ProfScope ps(e, e->sB, 2);
+#define G2(NTO_, PARTS_, IW_, EX_) launch_gemm2<NTO_, PARTS_, IW_, EX_>(e, packed, n_kb, kbps, splits, fill, outb, mode, partial, e->sB)
                 if (e->parts == 2) {
                     if (iw == 2) G2(1, 2, 2, true); else if (e->nto == 1) G2(1, 2, 1, true); else G2(2, 2, 1, true);
                 } else if (e->exact) {
@@ -1270,15 +1326,42 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
 #undef G2
                 if (partial) {
                     const int64_t n4 = sk_stride / 4;
-                    add_partials_kernel<<<2048, 256, 0, stream>>>((float4*)outb, (const float4*)partial, splits - 1, n4);
+                    add_partials_kernel<<<2048, 256, 0, e->sB>>>((float4*)outb, (const float4*)partial, splits - 1, n4);
                 }
             }
+            HIPCHK(hipEventRecord(e->evB[set], e->sB));
             first = false;
         }
     }
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->evDoneA, e->sA));
+    HIPCHK(hipEventRecord(e->evDoneB, e->sB));
+    e->pending = true;
+    if (!e->async_join) {
+        HIPCHK(hipStreamWaitEvent(caller, e->evDoneA, 0));
+        HIPCHK(hipStreamWaitEvent(caller, e->evDoneB, 0));
+        e->pending = false;
+    }
     return PYRHE_OK;
 }
+
+extern "C" int pyrhe_engine_set_async(pyrhe_engine_t* e, int enable) {
+    if (!e) return fail(PYRHE_EINVAL, "NULL engine");
+    e->async_join = enable != 0;
+    return PYRHE_OK;
+}
+
+extern "C" int pyrhe_engine_join(pyrhe_engine_t* e, void* stream_) {
+    if (!e) return fail(PYRHE_EINVAL, "NULL engine");
+    if (e->pending) {
+        HIPCHK(hipSetDevice(e->device));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)stream_, e->evDoneA, 0));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)stream_, e->evDoneB, 0));
+        e->pending = false;
+    }
+    return PYRHE_OK;
+}
+
 
 extern "C" int pyrhe_engine_block_stats(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                                         int32_t* out_sum, int32_t* out_nmiss, void* stream_) {

@@ -36,6 +36,8 @@ SYMBOLS = {
     "pyrhe_engine_set_rhs": (_i32, [_vp, _vp, C.POINTER(C.c_int32), _i32, _vp, _vp]),
     "pyrhe_engine_sketch_block": (_i32, [_vp, _vp, _i64, _vp, C.POINTER(_i64), _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "pyrhe_engine_block_stats": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "pyrhe_engine_set_async": (_i32, [_vp, _i32]),
+    "pyrhe_engine_join": (_i32, [_vp, _vp]),
     "pyrhe_decode_rows": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "pyrhe_synth_genotypes": (_i32, [_vp, _i64, _i64, _i64, _u64, _i64, _vp]),
     "pyrhe_engine_info": (_i64, [_vp, _i32]),
@@ -219,6 +221,15 @@ class SketchEngine:
                                                       1 if accumulate else 0, _stream_ptr(self.device)),
                    "pyrhe_engine_sketch_block")
         return out_sketch, out_norm, colsum
+
+    def set_async(self, enable: bool):
+        """Defer the per-call join: consecutive blocks then overlap (GEMM 1 of block j+1 beside GEMM 2 of block j)."""
+        _check(self.lib.pyrhe_engine_set_async(self._h, 1 if enable else 0), "pyrhe_engine_set_async")
+
+    def join(self):
+        """Order every un-joined sketch into the current torch stream."""
+        with torch.cuda.device(self.device):
+            _check(self.lib.pyrhe_engine_join(self._h, _stream_ptr(self.device)), "pyrhe_engine_join")
 
     def block_stats(self, packed: torch.Tensor):
         m = packed.shape[0]

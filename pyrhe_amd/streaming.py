@@ -284,16 +284,26 @@ class SketchRunner:
         outputs of engine pass p (``[nbin, n_sketch_p, n_pad]`` float32 / ``[nbin, n_norm_p]`` float64)."""
         any_missing = bool(self._check_missing and self._ingest_stats()[1].any())
         draw = self._uniform_stream(pass_index) if any_missing else None
-        for jl, j in enumerate(range(self.j0, self.j1)):
-            ent, offs = self._entries(j)
-            s, e = self.plan.range(j)
-            fill = None
-            if any_missing:
-                u = draw(j, e - s)                    # one uniform per SNP, missing or not (base.py:266,285)
-                fill = self._fill_for_block(j, u)
-            for p in range(self.n_pass):
-                self.engs[p].sketch_block(self._block_rows(j), ent, offs, fill=fill, out_sketch=out_sk[p][jl],
-                                          out_norm=out_norm[p][jl], accumulate=False)
+        pipelined = [eng for eng in self.engs if hasattr(eng, "set_async")]
+        for eng in pipelined:
+            eng.set_async(True)       # blocks write distinct outputs: let GEMM 1 of block j+1 overlap GEMM 2 of block j
+        fills = []                    # keep fill tensors alive until the join
+        try:
+            for jl, j in enumerate(range(self.j0, self.j1)):
+                ent, offs = self._entries(j)
+                s, e = self.plan.range(j)
+                fill = None
+                if any_missing:
+                    u = draw(j, e - s)                    # one uniform per SNP, missing or not (base.py:266,285)
+                    fill = self._fill_for_block(j, u)
+                    fills.append(fill)
+                for p in range(self.n_pass):
+                    self.engs[p].sketch_block(self._block_rows(j), ent, offs, fill=fill, out_sketch=out_sk[p][jl],
+                                              out_norm=out_norm[p][jl], accumulate=False)
+        finally:
+            for eng in pipelined:
+                eng.join()
+                eng.set_async(False)
 
     def _apply_U(self, v: torch.Tensor, f32: bool) -> torch.Tensor:
         """``W (Q (W^T v))`` for rows of v ``[..., n_pad]``; float32 like _compute_UXXz (base.py:407-408) or float64
