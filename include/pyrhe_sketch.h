@@ -109,14 +109,17 @@ int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packed, int64_t 
                               int32_t* out_colsum, int accumulate, void* stream);
 
 /*
- * Pipelining across calls.  Internally the engine runs GEMM 1 (+ the small per-SNP kernels) and GEMM 2 on two private
- * streams with two workspace sets, so GEMM 1 of the next sub-block overlaps GEMM 2 of the current one.  By default
+ * Pipelining across calls.  Internally the engine enqueues on private streams with two workspace sets (optionally
+ * GEMM 1 of the next sub-block beside GEMM 2 of the current one, pyrhe_engine_set_pipeline).  By default
  * every pyrhe_engine_sketch_block call ends by making the caller's stream wait for its results (plain stream
  * semantics).  pyrhe_engine_set_async(e, 1) defers that wait: results of all calls since the last join are ordered
  * into `stream` by pyrhe_engine_join(e, stream) -- the overlap then also spans consecutive blocks.  Output buffers of
  * un-joined calls must be distinct, inputs must stay unchanged until the join.
  */
 int pyrhe_engine_set_async(pyrhe_engine_t* e, int enable);
+/* enable = 1 puts GEMM 2 on a second internal stream so it overlaps GEMM 1 of the next sub-block (+3.5 % measured at
+ * N=500k; per-kernel timings then include the contention).  Default 0: both on one internal stream, in order. */
+int pyrhe_engine_set_pipeline(pyrhe_engine_t* e, int enable);
 int pyrhe_engine_join(pyrhe_engine_t* e, void* stream);
 
 /*

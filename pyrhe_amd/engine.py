@@ -38,6 +38,7 @@ SYMBOLS = {
     "pyrhe_engine_block_stats": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "pyrhe_engine_set_async": (_i32, [_vp, _i32]),
     "pyrhe_engine_join": (_i32, [_vp, _vp]),
+    "pyrhe_engine_set_pipeline": (_i32, [_vp, _i32]),
     "pyrhe_decode_rows": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "pyrhe_synth_genotypes": (_i32, [_vp, _i64, _i64, _i64, _u64, _i64, _vp]),
     "pyrhe_engine_info": (_i64, [_vp, _i32]),
@@ -99,13 +100,21 @@ def _require_gpu(device) -> torch.device:
     return device
 
 
-def upload_packed(packed_rows: np.ndarray, device) -> torch.Tensor:
-    """Host ``[m, ceil(N/4)]`` uint8 rows -> device ``[m, pitch]`` (zero padded)."""
+def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 30) -> torch.Tensor:
+    """Host ``[m, ceil(N/4)]`` uint8 rows (a NumPy array or a memory-mapped ``.bed`` body) -> device ``[m, pitch]``,
+    zero padded.  The rows are never decoded on the host; they are copied in ``chunk_bytes`` pieces through a pinned
+    staging buffer so a memory-mapped 100-GB file needs neither 100 GB of RAM nor one giant copy."""
     device = _require_gpu(device)
     m, rb = packed_rows.shape
     pitch = (rb + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
     out = torch.zeros((m, pitch), dtype=torch.uint8, device=device)
-    out[:, :rb] = torch.from_numpy(np.array(packed_rows, dtype=np.uint8, order="C")).to(device)
+    rows_per = max(1, chunk_bytes // max(rb, 1))
+    staging = torch.empty((min(rows_per, max(m, 1)), rb), dtype=torch.uint8).pin_memory() if m else None
+    for r0 in range(0, m, rows_per):
+        r1 = min(r0 + rows_per, m)
+        staging[: r1 - r0].numpy()[...] = packed_rows[r0:r1]
+        out[r0:r1, :rb].copy_(staging[: r1 - r0], non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()          # the staging buffer is reused
     return out
 
 
@@ -225,6 +234,9 @@ class SketchEngine:
     def set_async(self, enable: bool):
         """Defer the per-call join: consecutive blocks then overlap (GEMM 1 of block j+1 beside GEMM 2 of block j)."""
         _check(self.lib.pyrhe_engine_set_async(self._h, 1 if enable else 0), "pyrhe_engine_set_async")
+
+    def set_pipeline(self, enable: bool):
+        _check(self.lib.pyrhe_engine_set_pipeline(self._h, 1 if enable else 0), "pyrhe_engine_set_pipeline")
 
     def join(self):
         """Order every un-joined sketch into the current torch stream."""

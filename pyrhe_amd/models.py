@@ -119,7 +119,7 @@ class Base:
         packed = rio.read_bed_packed(geno_file + ".bed", self.num_indv_original, self.num_snp)
         r0 = self.plan.range(j0)[0] if j1 > j0 else 0
         r1 = self.plan.range(j1 - 1)[1] if j1 > j0 else 0
-        self.geno_dev = upload_packed(np.asarray(packed[r0:r1]), self.device)
+        self.geno_dev = upload_packed(packed[r0:r1], self.device)      # memmap slice -> HBM in pinned 1 GiB pieces
         self.engine = SketchEngine(self.num_indv_original, self.num_indv, max_entries=self.plan.max_block,
                                    precision=precision, device=self.device, sub_snps=sub_snps)
         self._runner = None
