@@ -39,7 +39,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n-indv", type=int, default=500_000)
     ap.add_argument("--n-snp", type=int, default=1_000_000)
     ap.add_argument("--jn", type=int, default=100)

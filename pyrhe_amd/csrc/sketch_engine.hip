@@ -98,9 +98,9 @@ __device__ __forceinline__ uint32_t unpack(uint32_t x) {
     constexpr float sc = T == 0 ? 1.0f : (T == 1 ? 0.25f : (T == 2 ? 0.0625f : 0.015625f));
     // one v_and_or_b32 (VOP3 takes no literals on gfx9: the mask must sit in a VGPR, the magic in an SGPR; hipcc
     // otherwise emits v_and + v_or with two literals)
-    uint32_t m;
-    const uint32_t vmask = mask;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(m) : "v"(x), "v"(vmask), "s"(0x64006400u));
+    uint32_t vmask = mask;
+    asm("" : "+v"(vmask));            // opaque VGPR: lets instruction selection pick v_and_or_b32 (mask VGPR, magic SGPR)
+    const uint32_t m = (x & vmask) | 0x64006400u;
     const half2v hx = __builtin_bit_cast(half2v, m);
     const half2v s = {(_Float16)sc, (_Float16)sc};
     const half2v b = {(_Float16)(-1024.0f * sc), (_Float16)(-1024.0f * sc)};
@@ -656,7 +656,10 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const uint8_t* __restrict
     for (int i = threadIdx.x; i < (kb1 - kb0) * 32; i += 256) s_rows[i] = rows32[(int64_t)kb0 * 32 + i];
     __syncthreads();
     if (grp * (256 * IW) >= n_pad) return;
-    const uint8_t* colp = packed + grp * (64 * IW) + n * (4 * IW);
+    // 32-bit byte offsets: row * pitch with the full-rate 24-bit multiply (rows, pitch < 2^24 and rows * pitch < 2^32
+    // are checked on the host); a 64-bit multiply-add per row is four quarter-rate VALU ops per load otherwise
+    const uint32_t coloff = (uint32_t)(grp * (64 * IW) + n * (4 * IW));
+    const uint32_t pitch24 = (uint32_t)pitch;
 
     float4v acc[NTO][NU];
 #pragma unroll
@@ -674,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const uint8_t* __restrict
         const int rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint8_t* p = colp + (int64_t)rr[j] * pitch;
+            const uint8_t* p = packed + (size_t)(__umul24((uint32_t)rr[j], pitch24) + coloff);
             if (IW == 1) {
                 ww[j][0] = *reinterpret_cast<const uint32_t*>(p);
             } else {
@@ -1208,6 +1211,9 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                         (long long)(offsets_host[b + 1] - offsets_host[b]), (long long)e->max_entries);
     }
     if (offsets_host[nbin] > 0 && !entries) return fail(PYRHE_EINVAL, "entries is NULL");
+    if (n_rows >= (1 << 24) || e->pitch >= (1 << 24) || (uint64_t)n_rows * (uint64_t)e->pitch >= (1ull << 32))
+        return fail(PYRHE_EINVAL, "block of %lld rows x %lld bytes exceeds the 32-bit row offsets of one call; split it",
+                    (long long)n_rows, (long long)e->pitch);
     hipStream_t caller = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(e->device));
     // Serial mode (default): everything goes to the caller's stream, no events.  Pipelined mode: private streams A
