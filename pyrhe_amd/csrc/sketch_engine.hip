@@ -803,6 +803,194 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const uint8_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// int8 variant of GEMM 2 (precision i8x3, one tile of <= 16 sketch columns): W = D V as three int8 limbs (per-column
+// power-of-two scale, |x| < 64), one int32 accumulator set per limb, K = 64 SNPs per step.
+// Lane (n, q) reads dword n of rows 16q..16q+15; MFMA u needs, per lane, the crumb u of those 16 rows as 16 bytes:
+// rows are spread to bytes ((v >> 2t), masked after the transpose) and 4x4 byte blocks are transposed across row
+// quads with v_perm_b32 (8 per block).  Wimg layout: [kb64][limb 3][lane 64][16 bytes], lane = q*16 + c,
+// byte j <-> entry 64 kb + 16 q + j.
+// ------------------------------------------------------------------------------------------------
+__global__ void mid2_i8_kernel(const float* __restrict__ Wtmp, const float* __restrict__ mu, int n_entries, int n_kb,
+                               int n_sketch, const uint32_t* __restrict__ wmax_bits, int4v* __restrict__ wimg,
+                               double* __restrict__ corr, float* __restrict__ wscale) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = gid & 63;
+    int64_t rest = gid >> 6;
+    const int limb = rest % 3;
+    const int64_t kb = rest / 3;
+    if (kb >= n_kb) return;
+    const int c = lane & 15, q = lane >> 4;
+    const float s = c < n_sketch ? i8_scale(__uint_as_float(wmax_bits[c])) : 1.0f;
+    uint32_t w[4];
+    double acc = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = kb * 64 + q * 16 + p * 4 + r;
+            float x = 0.f, m = 0.f;
+            if (e < n_entries && c < n_sketch) {
+                x = Wtmp[(int64_t)e * n_sketch + c] * s;
+                m = mu[e];
+            }
+            const float a1 = rintf(x);
+            const float r1 = (x - a1) * 128.0f;
+            const float a2 = rintf(r1);
+            const float a3 = rintf((r1 - a2) * 128.0f);
+            const float a = limb == 0 ? a1 : (limb == 1 ? a2 : a3);
+            acc += (double)m * (double)a * (limb == 0 ? 1.0 : (limb == 1 ? 1.0 / 128.0 : 1.0 / 16384.0));
+            word |= ((uint32_t)(int)a & 0xFFu) << (8 * r);
+        }
+        w[p] = word;
+    }
+    wimg[gid] = (int4v){(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if (q == 0 && c < n_sketch) atomicAdd(&corr[c], acc);
+    if (kb == 0 && limb == 0 && q == 0) wscale[c] = s;
+}
+
+template <bool MISSING>
+__global__ __launch_bounds__(256, 1) void gemm2_i8_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
+                                                          const int32_t* __restrict__ rows64, int n_kb,
+                                                          int kb_per_split, const float* __restrict__ fill,
+                                                          const int4v* __restrict__ wimg,
+                                                          const double* __restrict__ corr,
+                                                          const float* __restrict__ wscale,
+                                                          const float* __restrict__ keep, int n_sketch,
+                                                          int64_t n_pad, float* __restrict__ out, int mode,
+                                                          float* __restrict__ partial) {
+    constexpr int NS = 2;
+    extern __shared__ __attribute__((aligned(16))) int32_t s_rows[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    const int kb0 = blockIdx.y * kb_per_split;
+    const int kb1 = min(kb0 + kb_per_split, n_kb);
+    if (kb0 >= kb1) return;
+    for (int i = threadIdx.x; i < (kb1 - kb0) * 64; i += 256) s_rows[i] = rows64[(int64_t)kb0 * 64 + i];
+    __syncthreads();
+    if (grp * 256 >= n_pad) return;
+    const uint32_t coloff = (uint32_t)(grp * 64 + n * 4);
+    const uint32_t pitch24 = (uint32_t)pitch;
+
+    int4v acc[3][16];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[l][u] = (int4v){0, 0, 0, 0};
+
+    uint32_t w[NS][16];
+    int4v a[NS][3];
+    int fl[NS][16];
+    auto issue = [&](int kb, uint32_t (&ww)[16], int4v (&aa)[3], int (&ff)[16]) {
+        const int4* rp = reinterpret_cast<const int4*>(s_rows + (kb - kb0) * 64 + q * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int4 r4 = rp[i];
+            const int rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ww[4 * i + r] = *reinterpret_cast<const uint32_t*>(packed + (size_t)(__umul24((uint32_t)rr[r], pitch24) + coloff));
+                if (MISSING) ff[4 * i + r] = (int)fill[rr[r]];
+            }
+        }
+        const int4v* wf = wimg + (int64_t)kb * (3 * 64) + lane;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) aa[l] = wf[l * 64];
+    };
+    auto compute = [&](const uint32_t (&ww)[16], const int4v (&aa)[3], const int (&ff)[16]) {
+        int4v opnd[16];      // opnd[u][p] = bytes (row 4p .. 4p+3) of crumb u
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint32_t v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = value_code(ww[4 * p + r]);
+                if (MISSING) v[r] = apply_fill(v[r], missing_mask(ww[4 * p + r]), ff[4 * p + r]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // bytes of (v >> 2t): crumbs t, t+4, t+8, t+12 in their low 2 bits (masked after the transpose)
+                const uint32_t x0 = v[0] >> (2 * t), x1 = v[1] >> (2 * t), x2 = v[2] >> (2 * t), x3 = v[3] >> (2 * t);
+                const uint32_t l01 = __builtin_amdgcn_perm(x1, x0, 0x05010400u);   // [x0.b0, x1.b0, x0.b1, x1.b1]
+                const uint32_t h01 = __builtin_amdgcn_perm(x1, x0, 0x07030602u);   // [x0.b2, x1.b2, x0.b3, x1.b3]
+                const uint32_t l23 = __builtin_amdgcn_perm(x3, x2, 0x05010400u);
+                const uint32_t h23 = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
+                opnd[t + 0][p] = (int)(__builtin_amdgcn_perm(l23, l01, 0x05040100u) & 0x03030303u);   // byte 0 of every row
+                opnd[t + 4][p] = (int)(__builtin_amdgcn_perm(l23, l01, 0x07060302u) & 0x03030303u);   // byte 1
+                opnd[t + 8][p] = (int)(__builtin_amdgcn_perm(h23, h01, 0x05040100u) & 0x03030303u);   // byte 2
+                opnd[t + 12][p] = (int)(__builtin_amdgcn_perm(h23, h01, 0x07060302u) & 0x03030303u);  // byte 3
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                acc[l][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aa[l], opnd[u], acc[l][u], 0, 0, 0);
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) issue(min(kb0 + s, kb1 - 1), w[s], a[s], fl[s]);
+    int kb = kb0;
+    for (; kb + NS <= kb1; kb += NS) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            compute(w[s], a[s], fl[s]);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(min(kb + s + NS, kb1 - 1), w[s], a[s], fl[s]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (kb < kb1) compute(w[0], a[0], fl[0]);
+    // epilogue: D[row = column c = 4q + reg][col = n]; MFMA u <-> sample 256 grp + 16 n + u
+    const int64_t i0 = grp * 256 + n * 16;
+    float kp[16];
+#pragma unroll
+    for (int u4 = 0; u4 < 4; ++u4) {
+        const float4 k4 = *reinterpret_cast<const float4*>(keep + i0 + 4 * u4);
+        kp[4 * u4] = k4.x; kp[4 * u4 + 1] = k4.y; kp[4 * u4 + 2] = k4.z; kp[4 * u4 + 3] = k4.w;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int c = 4 * q + reg;
+        if (c >= n_sketch) continue;
+        const float cr = blockIdx.y == 0 ? (float)corr[c] : 0.f;
+        const float inv = 1.0f / wscale[c];
+        float* dst = out + (int64_t)c * n_pad + i0;
+        int md = mode;
+        if (partial && blockIdx.y > 0) {
+            dst = partial + ((int64_t)(blockIdx.y - 1) * n_sketch + c) * n_pad + i0;
+            md = 0;
+        }
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+            float vv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = 4 * u4 + i;
+                const float x = (float)acc[0][u][reg] + (float)acc[1][u][reg] * (1.0f / 128.0f) + (float)acc[2][u][reg] * (1.0f / 16384.0f);
+                vv[i] = (x - cr) * inv * kp[u];
+            }
+            float4* d4 = reinterpret_cast<float4*>(dst + 4 * u4);
+            if (md == 0) {
+                *d4 = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            } else if (md == 1) {
+                float4 o = *d4;
+                o.x += vv[0]; o.y += vv[1]; o.z += vv[2]; o.w += vv[3];
+                *d4 = o;
+            } else {
+                atomicAdd(dst + 4 * u4 + 0, vv[0]);
+                atomicAdd(dst + 4 * u4 + 1, vv[1]);
+                atomicAdd(dst + 4 * u4 + 2, vv[2]);
+                atomicAdd(dst + 4 * u4 + 3, vv[3]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------------------
 // pad an entry sub-list to a multiple of 32 (pad rows read row rows[0]; their W is zero)
@@ -1013,7 +1201,7 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     const size_t oWtmp = carve(S * ncolmax * sizeof(float));
     const size_t oWscale = carve(ncolmax * sizeof(float));
     const size_t oWfrag = carve((S / 32) * e->parts * kMaxTiles * 64 * sizeof(half8));
-    const size_t oRows = carve(S * sizeof(int32_t));
+    const size_t oRows = carve((S + 64) * sizeof(int32_t));
     e->ws_bytes = off;
     for (int i = 0; i < 2; ++i) {
         uint8_t* base = nullptr;
@@ -1251,8 +1439,14 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
         for (int64_t s0 = 0; s0 < n_b; s0 += e->sub_snps) {
             const int n = (int)std::min<int64_t>(e->sub_snps, n_b - s0);
             const int32_t* rows = entries + offsets_host[b] + s0;
-            const int n32 = (n + 31) / 32 * 32;
-            const int n_kb = n32 / 32;
+            // int8 GEMM 2 (K = 64 SNPs per step, three int32 accumulator sets): correct (agrees with the fp16 hi+lo form
+            // to 4e-10 on sigma^2) but measured SLOWER at N=500k -- 40.4 ms vs 32.9 ms per pass: 468 registers pin it to one
+            // wave per SIMD and the 16x16 crumb transpose costs 240 v_perm/v_and per step.  Kept opt-in (PYRHE_G2_I8=1).
+            static const bool g2i8_env = getenv("PYRHE_G2_I8") && atoi(getenv("PYRHE_G2_I8")) != 0;
+            const bool g2i8 = g2i8_env && e->i8 && e->nto == 1 && e->n_sketch > 0;
+            const int kstep = g2i8 ? 64 : 32;
+            const int n32 = (n + kstep - 1) / kstep * kstep;
+            const int n_kb = n32 / kstep;
             const int set = (int)(e->sub_counter & 1);
             e->use_set(set);
             if (piped && e->sub_counter >= 2) HIPCHK(hipStreamWaitEvent(e->sA, e->evB[set], 0));   // GEMM 2 of sub-block g-2 is done with this set
@@ -1295,7 +1489,10 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                 if (e->n_sketch) {
                     const int64_t threads = (int64_t)n_kb * e->parts * e->nto * 64;
                     const unsigned grid = (unsigned)((threads + 255) / 256);
-                    if (e->parts == 2) mid2_kernel<2><<<grid, 256, 0, stream>>>(e->Wtmp, e->mu, n, n_kb, e->n_sketch, e->nto, e->wmax, e->wfrag, e->corr, e->wscale);
+                    if (g2i8) {
+                        const int64_t th = (int64_t)n_kb * 3 * 64;
+                        mid2_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(e->Wtmp, e->mu, n, n_kb, e->n_sketch, e->wmax, (int4v*)e->wfrag, e->corr, e->wscale);
+                    } else if (e->parts == 2) mid2_kernel<2><<<grid, 256, 0, stream>>>(e->Wtmp, e->mu, n, n_kb, e->n_sketch, e->nto, e->wmax, e->wfrag, e->corr, e->wscale);
                     else mid2_kernel<1><<<grid, 256, 0, stream>>>(e->Wtmp, e->mu, n, n_kb, e->n_sketch, e->nto, e->wmax, e->wfrag, e->corr, e->wscale);
                 }
                 if (e->n_norm) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc, normb, e->n_norm, accumulate || !first);
@@ -1313,11 +1510,12 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                 // (measured at N=500k: one fp16 pass is faster with 512-sample waves even at 1 wave/SIMD, the hi+lo
                 // mode with 256-sample waves at 2 waves/SIMD)
                 int iw = (e->nto == 1 && e->parts == 1 && e->n_pad >= 2048 * 160) ? 2 : 1;
+                if (g2i8) iw = 1;
                 if (const char* ev = getenv("PYRHE_G2_IW")) iw = atoi(ev) == 2 && e->nto == 1 ? 2 : 1;
                 const int gx = (int)((e->n_pad + 1024 * iw - 1) / (1024 * iw));
                 int splits = gx >= 192 ? 1 : std::min(16, (512 + gx - 1) / gx);
                 if (const char* ev = getenv("PYRHE_G2_SPLITS")) splits = atoi(ev);
-                splits = std::max(splits, (n_kb + 511) / 512);        // row list of a K range lives in LDS: <= 64 KiB
+                splits = std::max(splits, (n_kb + (g2i8 ? 255 : 511)) / (g2i8 ? 256 : 512));   // row list of a K range lives in LDS: <= 64 KiB
                 splits = std::max(1, std::min(splits, n_kb));
                 const int kbps = (n_kb + splits - 1) / splits;
                 splits = (n_kb + kbps - 1) / kbps;
@@ -1342,7 +1540,12 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                 }
                 ProfScope ps(e, sB2, 2);
 #define G2(NTO_, PARTS_, IW_, EX_) launch_gemm2<NTO_, PARTS_, IW_, EX_>(e, packed, n_kb, kbps, splits, fill, outb, mode, partial, sB2)
-                if (e->parts == 2) {
+                if (g2i8) {
+                    dim3 grid((unsigned)((e->n_pad + 1023) / 1024), splits);
+                    const size_t lds = (size_t)kbps * 256;
+                    if (fill) gemm2_i8_kernel<true><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outb, mode, partial);
+                    else gemm2_i8_kernel<false><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outb, mode, partial);
+                } else if (e->parts == 2) {
                     if (iw == 2) G2(1, 2, 2, true); else if (e->nto == 1) G2(1, 2, 1, true); else G2(2, 2, 1, true);
                 } else if (e->exact) {
                     if (iw == 2) G2(1, 1, 2, true); else if (e->nto == 1) G2(1, 1, 1, true); else G2(2, 1, 1, true);
