@@ -68,8 +68,9 @@ def _import_reference():
         sys.path.insert(0, REFERENCE)
     from pyrhe.src.models.rhe import RHE, StreamingRHE
     from pyrhe.src.models.genie import GENIE
+    from pyrhe.src.models.rhe_dom import RHE_DOM
     from pyrhe.src.util.logger import Logger
-    return RHE, StreamingRHE, GENIE, Logger
+    return RHE, StreamingRHE, GENIE, Logger, RHE_DOM
 
 
 CASES = [
@@ -99,13 +100,17 @@ CASES = [
     dict(name="genie_gxe_nxe_cov", cohort=dict(n_indv=403, n_snp=240, seed=21, nbin=1, with_env=True, with_cov=3), model="GENIE",
          kw=dict(num_jack=10, num_random_vec=10, seed=10, genie_model="G+GxE+NxE")),
     # genie_model="G" has no reference behaviour: GENIE.aggregate indexes env[:, -1 - 2*nbin] and raises IndexError
+    dict(name="rhe_dom_2bin", cohort=dict(n_indv=403, n_snp=240, seed=23, nbin=2), model="RHE_DOM",
+         kw=dict(num_jack=10, num_random_vec=10, seed=12)),
+    dict(name="rhe_dom_cov", cohort=dict(n_indv=403, n_snp=240, seed=24, nbin=1, with_cov=3), model="RHE_DOM",
+         kw=dict(num_jack=10, num_random_vec=10, seed=13)),
     dict(name="genie_gxe_cov", cohort=dict(n_indv=403, n_snp=240, seed=19, nbin=1, with_env=True, with_cov=3), model="GENIE",
          kw=dict(num_jack=10, num_random_vec=10, seed=8, genie_model="G+GxE")),
 ]
 
 
 def run_case(case, classes):
-    RHE, StreamingRHE, GENIE, Logger = classes
+    RHE, StreamingRHE, GENIE, Logger, RHE_DOM = classes
     cohort = fixtures.make_cohort(case["name"], **case["cohort"])
     out = fixtures.cohort_to_npz_dict(cohort)
     kw = dict(case["kw"])
@@ -121,6 +126,9 @@ def run_case(case, classes):
         elif case["model"] == "GENIE":
             params.update(multiprocessing=False, num_workers=1, env_file=paths["env"], genie_model=kw["genie_model"], model="genie")
             cls = GENIE
+        elif case["model"] == "RHE_DOM":
+            params.update(multiprocessing=False, num_workers=1, model="rhe_dom")
+            cls = RHE_DOM
         else:
             params.update(multiprocessing=False, num_workers=1)
             cls = RHE

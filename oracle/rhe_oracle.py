@@ -99,6 +99,22 @@ def standardize_geno(G: np.ndarray) -> np.ndarray:
     return (G - means) * inv_sd
 
 
+def encode_geno_dom(G: np.ndarray):
+    """Dominance encoding (rhe_dom.py:23-41): 0 -> 0, 1 -> 2p, 2 -> 4p - 2 with p = mean/2 (float32), stored float64."""
+    maf = np.mean(G, axis=0) / 2
+    enc = np.zeros_like(G, dtype=np.float64)
+    enc += (G == 1) * (2 * maf[np.newaxis, :])
+    enc += (G == 2) * (4 * maf[np.newaxis, :] - 2)
+    return enc, maf
+
+
+def standardize_geno_dom(enc: np.ndarray, maf: np.ndarray) -> np.ndarray:
+    """(enc - mean) / (2 p (1 - p))  (rhe_dom.py:15-21)."""
+    means = np.mean(enc, axis=0)
+    inv = 1 / (2 * maf * (1 - maf))
+    return (enc - means) * inv
+
+
 # --------------------------------------------------------------------------- the four sketches
 def _t32(x: np.ndarray) -> torch.Tensor:
     """``to_tensor``: every operand becomes a float32 CPU tensor (pyrhe/src/util/mat_mul.py:4-15)."""
@@ -152,6 +168,7 @@ class Problem:
     genie_model: Optional[str] = None  # None (RHE) | "G" | "G+GxE"
     impute: str = "binary"
     Z: Optional[np.ndarray] = None     # [N, k] float64 probe vectors (all_zb)
+    dom: bool = False                  # RHE_DOM: a dominance estimate per bin after the additive ones
 
     def __post_init__(self):
         if self.cov is not None:
@@ -181,7 +198,9 @@ class Problem:
 
     @property
     def n_est(self) -> int:
-        """genie.py:26-34 (one environment)."""
+        """genie.py:26-34 (one environment); rhe_dom.py:7-9."""
+        if self.dom:
+            return 2 * self.nbin
         return self.nbin * (2 if self.has_gxe else 1) + (1 if self.has_nxe else 0)
 
     def len_bin(self) -> np.ndarray:
@@ -190,6 +209,8 @@ class Problem:
     def m_last_row(self) -> np.ndarray:
         """genie.py:36-44."""
         lb = self.len_bin()
+        if self.dom:                                  # rhe_dom.py:11-13
+            return np.concatenate([lb, lb])
         parts = [lb] + ([lb] if self.has_gxe else []) + ([np.ones(1, lb.dtype)] if self.has_nxe else [])
         return np.concatenate(parts)
 
@@ -242,6 +263,9 @@ def sketch_block(p: Problem, j: int, reseed: bool) -> BlockSketch:
 
     for b_idx, Gb in enumerate(bins):
         one(b_idx, standardize_geno(Gb))
+    if p.dom:                                           # rhe_dom.py:56-68
+        for b_idx, Gb in enumerate(bins):
+            one(b_idx + p.nbin, standardize_geno_dom(*encode_geno_dom(Gb)))
     if p.has_gxe:                                       # genie.py:59-75 ; k_gxe = (e+1)*k + nbin, e = 0
         for b_idx, Gb in enumerate(bins):
             Xs = standardize_geno(Gb)
@@ -479,6 +503,17 @@ def rhe_results(p: Problem, st: State, method: str = "QR") -> dict:
         "enrichment_total_overlap": enro[-1], "enrichment_errs_overlap": jackknife_se(enro[:-1], jn),
         "sigma_jack": sj, "T": Ts, "q": qs,
     }
+
+
+def rhe_dom_results(p: Problem, st: State, method: str = "QR") -> dict:
+    """The result dict of ``RHE_DOM.run`` (rhe_dom.py:76-117): 2 nbin estimates, non-overlapping h2 + enrichment only."""
+    sj, stot, _, _, Ts, qs = estimate(p, st, method)
+    ne, jn = p.n_est, p.n_jack
+    h2 = h2_nonoverlapping(np.vstack([sj, stot[None]]), ne)
+    enr = enrichment(h2, st.M, ne)
+    return {"sigma_ests_total": stot, "sig_errs": jackknife_se(sj, jn), "h2_total": h2[-1],
+            "h2_errs": jackknife_se(h2[:-1], jn), "enrichment_total": enr[-1],
+            "enrichment_errs": jackknife_se(enr[:-1], jn), "sigma_jack": sj, "T": Ts, "q": qs}
 
 
 # --------------------------------------------------------------------------- GENIE result shaping

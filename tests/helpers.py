@@ -11,6 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RHE_CASES = ["rhe_1bin_nocov", "rhe_3bin_nocov_rem", "rhe_3bin_cov", "rhe_1bin_missing",
              "rhe_1bin_missing_mean", "rhe_1bin_n1024", "rhe_2bin_jn1", "rhe_1bin_2traits"]
 STREAMING_CASES = ["srhe_3bin_cov"]
+DOM_CASES = ["rhe_dom_2bin", "rhe_dom_cov"]
 GENIE_CASES = ["genie_gxe_2bin", "genie_gxe_cov", "genie_gxe_nxe_2bin", "genie_gxe_nxe_cov"]
 RESULT_KEYS_RHE = ["sigma_ests_total", "sig_errs", "h2_total", "h2_errs", "enrichment_total", "enrichment_errs",
                    "h2_total_overlap", "h2_errs_overlap", "enrichment_total_overlap", "enrichment_errs_overlap"]
@@ -32,6 +33,8 @@ def oracle_problem(z, trait=0):
                   n_jack=int(z["param_num_jack"]), k=int(z["param_num_random_vec"]), seed=int(z["param_seed"]),
                   missing_indv=miss, cov=cov,
                   impute=str(z["param_geno_impute_method"]) if "param_geno_impute_method" in z else "binary")
+    if str(z["param_model"]) == "RHE_DOM":
+        p.dom = True
     if "param_genie_model" in z:
         p.genie_model = str(z["param_genie_model"])
         p.env = c.env.reshape(-1, 1)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import rhe_oracle as O
-from tests.helpers import (GENIE_CASES, RESULT_KEYS_GENIE, RESULT_KEYS_RHE, RHE_CASES, STREAMING_CASES,
+from tests.helpers import (DOM_CASES, GENIE_CASES, RESULT_KEYS_GENIE, RESULT_KEYS_RHE, RHE_CASES, STREAMING_CASES,
                            load_golden, oracle_problem)
 
 RTOL = 1e-9
@@ -69,6 +69,21 @@ def test_genie_gxe(name):
     assert close(st.XXz[:, p.n_jack], z["ref_t0_XXz_total"])
     assert close(st.yXXy[:, p.n_jack], z["ref_t0_yXXy_total"])
     r = O.genie_results(p, st)
+    assert close(r["T"], z["ref_t0_T"])
+    for k in RESULT_KEYS_GENIE:
+        assert close(r[k], z["ref_t0_res_" + k]), k
+
+
+@pytest.mark.parametrize("name", DOM_CASES)
+def test_rhe_dom(name):
+    """RHE_DOM: additive + dominance estimate per bin (rhe_dom.py); result dict has the six GENIE-style keys."""
+    z = load_golden(name)
+    p, _ = oracle_problem(z)
+    st = O.precompute(p)
+    assert np.array_equal(st.M, z["ref_t0_M"])
+    assert close(np.stack([b.XXz for b in st.blocks], axis=1), z["ref_t0_XXz_blocks"])
+    assert close(st.yXXy[:, p.n_jack], z["ref_t0_yXXy_total"])
+    r = O.rhe_dom_results(p, st)
     assert close(r["T"], z["ref_t0_T"])
     for k in RESULT_KEYS_GENIE:
         assert close(r[k], z["ref_t0_res_" + k]), k
