@@ -109,6 +109,18 @@ int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packed, int64_t 
                               int32_t* out_colsum, int accumulate, void* stream);
 
 /*
+ * As pyrhe_engine_sketch_block, plus the DOMINANCE sketches of RHE_DOM for the same entry lists
+ * (pyrhe/src/models/rhe_dom/rhe_dom.py:15-41,56-68 and streaming_rhe_dom.py): with p = mean/2, the encoding
+ * enc(0,1,2) = (0, 2p, 4p-2) and X_dom = (enc - mean(enc)) / (2p(1-p)),
+ *   out_sketch_dom[b][c][:] (+)= X_dom (X_dom^T R[c]),   out_norm_dom[b][c] (+)= || X_dom^T R[c] ||^2.
+ * Costs one extra GEMM 1 (view 2*[g==2]) and two extra GEMM 2 launches per entry list.   Asynchronous on `stream`.
+ */
+int pyrhe_engine_sketch_block_dom(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
+                                  const int32_t* entries, const int64_t* offsets_host, int nbin,
+                                  const float* fill, float* out_sketch, double* out_norm,
+                                  float* out_sketch_dom, double* out_norm_dom, int accumulate, void* stream);
+
+/*
  * Pipelining across calls.  Internally the engine enqueues on private streams with two workspace sets (optionally
  * GEMM 1 of the next sub-block beside GEMM 2 of the current one, pyrhe_engine_set_pipeline).  By default
  * every pyrhe_engine_sketch_block call ends by making the caller's stream wait for its results (plain stream

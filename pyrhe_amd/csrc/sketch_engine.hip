@@ -91,9 +91,11 @@ __device__ __forceinline__ uint32_t apply_fill(uint32_t v, uint32_t miss, int fi
 //     fp16 rounding of this mode, too coarse for the hi+lo mode.
 //  EXACT = true (precision f16x2): (x & mask) | 0x6400 is the NORMAL fp16 number 1024 + c * 4^t; one packed fma
 //     h * 4^-t - 1024 * 4^-t returns c exactly (3 VALU ops per register instead of 1).
-template <int T, bool EXACT>
+// GV (genotype view): 0 = allele count c; 1 = 2 * [c == 2] (bit 1 of the value code), the second operand of the
+// dominance encoding of RHE_DOM (rhe_dom.py:23-41: enc = 2p c - 2 [c == 2]).
+template <int T, bool EXACT, int GV = 0>
 __device__ __forceinline__ uint32_t unpack(uint32_t x) {
-    constexpr uint32_t mask = 0x00030003u << (2 * T);
+    constexpr uint32_t mask = (GV ? 0x00020002u : 0x00030003u) << (2 * T);
     if (!EXACT) return x & mask;
     constexpr float sc = T == 0 ? 1.0f : (T == 1 ? 0.25f : (T == 2 ? 0.0625f : 0.015625f));
     // one v_and_or_b32 (VOP3 takes no literals on gfx9: the mask must sit in a VGPR, the magic in an SGPR; hipcc
@@ -108,13 +110,13 @@ __device__ __forceinline__ uint32_t unpack(uint32_t x) {
 }
 // 8 genotypes (crumbs 0..3 of both 16-bit halves of x) -> MFMA operand fragment.
 // k-slot j of the fragment = crumb (j>>1) of half (j&1) (times 4^(j>>1) * 2^-24 when !EXACT).
-template <bool EXACT>
+template <bool EXACT, int GV = 0>
 __device__ __forceinline__ half8 unpack4(uint32_t x) {
     Frag f;
-    f.u[0] = unpack<0, EXACT>(x);
-    f.u[1] = unpack<1, EXACT>(x);
-    f.u[2] = unpack<2, EXACT>(x);
-    f.u[3] = unpack<3, EXACT>(x);
+    f.u[0] = unpack<0, EXACT, GV>(x);
+    f.u[1] = unpack<1, EXACT, GV>(x);
+    f.u[2] = unpack<2, EXACT, GV>(x);
+    f.u[3] = unpack<3, EXACT, GV>(x);
     return f.h;
 }
 
@@ -217,7 +219,7 @@ __global__ void prep_keepmask_kernel(const float* __restrict__ keep, int64_t n_p
 // a double-buffered LDS ring; the packed genotype words of step s+1 are in flight while step s is
 // decoded and multiplied (register prefetch, one barrier per step).
 // ------------------------------------------------------------------------------------------------
-template <int NTL, int PARTS, bool EXACT, bool MISSING>
+template <int NTL, int PARTS, bool EXACT, bool MISSING, int GV = 0>
 __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                     const int32_t* __restrict__ rows, int n_entries,
                                                     const float* __restrict__ fill,
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
                 for (int h = 0; h < 2; ++h) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const half8 a = unpack4<EXACT>(h ? (v[t] >> 8) : v[t]);
+                        const half8 a = unpack4<EXACT, GV>(h ? (v[t] >> 8) : v[t]);
 #pragma unroll
                         for (int p = 0; p < PARTS; ++p)
 #pragma unroll
@@ -408,7 +410,7 @@ __global__ void prep_rimg_i8_kernel(const float* __restrict__ R, const float* __
     if (chunk == 0 && d == 0 && limb == 0 && q == 0) scale[c] = s;
 }
 
-template <int NTL, bool MISSING>
+template <int NTL, bool MISSING, int GV = 0>
 __global__ __launch_bounds__(256) void gemm1_i8_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                        const int32_t* __restrict__ rows, int n_entries,
                                                        const float* __restrict__ fill,
@@ -478,8 +480,8 @@ __global__ __launch_bounds__(256) void gemm1_i8_kernel(const uint8_t* __restrict
                     const uint32_t w = d == 0 ? gg[t][ch].x : (d == 1 ? gg[t][ch].y : (d == 2 ? gg[t][ch].z : gg[t][ch].w));
                     uint32_t v = value_code(w);
                     if (MISSING) v = apply_fill(v, missing_mask(w), fillv[t]);
-                    const int4v a = {(int)(v & 0x03030303u), (int)((v >> 2) & 0x03030303u),
-                                     (int)((v >> 4) & 0x03030303u), (int)((v >> 6) & 0x03030303u)};
+                    constexpr uint32_t bm = GV ? 0x02020202u : 0x03030303u;
+                    const int4v a = {(int)(v & bm), (int)((v >> 2) & bm), (int)((v >> 4) & bm), (int)((v >> 6) & bm)};
 #pragma unroll
                     for (int l = 0; l < 3; ++l)
 #pragma unroll
@@ -574,6 +576,73 @@ __global__ void mid1_kernel(const float* __restrict__ P, float pscale, int i8, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// mid (dominance): RHE_DOM's second estimate per bin (rhe_dom.py:15-41).  With H = [g == 1], T = [g == 2]:
+//   enc = a H + b T,  a = 2p, b = 4p - 2, p = mean(g)/2 (float32);  X_dom = (enc - m) t,  m = mean(enc),
+//   t = 1/(2p(1-p)) (float32).  Since H = G - 2T:   X_dom^T r = t (a G^T r - 2 T^T r - m 1^T r)
+//                                                   X_dom v   = G (t a v) + 2T (-t v) - 1 (m t v)
+// PG is GEMM 1's output for the allele-count view, PT for the 2*[g==2] view (so PT = 2 T^T r, its ones column
+// 2 n2).  Outputs: W1 = t a V (for the G view), W2 = -t V (for the 2T view), cmu = m / a (rank-1 coefficient
+// relative to W1), sum V^2 for the norm columns.
+// ------------------------------------------------------------------------------------------------
+__global__ void mid_dom1_kernel(const float* __restrict__ PG, const float* __restrict__ PT, float pscale, int i8,
+                                int n_entries, int ncol_p, int n_sketch, int n_norm, const float* __restrict__ scale,
+                                const double* __restrict__ csum, float n_keep, float* __restrict__ cmu,
+                                float* __restrict__ W1, float* __restrict__ W2, uint32_t* __restrict__ wmax1,
+                                uint32_t* __restrict__ wmax2, double* __restrict__ norm_acc) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ones = n_sketch + n_norm;
+    const bool live = e < n_entries;
+    auto rd = [&](const float* P, int c) -> double {
+        if (i8) {
+            const int* Pi = reinterpret_cast<const int*>(P) + (int64_t)e * 3 * ncol_p + c;
+            return (double)Pi[0] + (double)Pi[ncol_p] * (1.0 / 128.0) + (double)Pi[2 * ncol_p] * (1.0 / 16384.0);
+        }
+        return (double)P[(int64_t)e * ncol_p + c] * (double)pscale;
+    };
+    float a = 0.f, t = 0.f;
+    double m = 0.0, b = 0.0;
+    if (live) {
+        const double sumG = rd(PG, ones), n2 = 0.5 * rd(PT, ones);     // exact integers
+        const double n1 = sumG - 2.0 * n2;
+        const float maf = ((float)sumG / n_keep) / 2.0f;                // np.mean(geno) / 2, float32
+        a = 2.0f * maf;
+        const float bf = 4.0f * maf - 2.0f;
+        b = (double)bf;
+        t = 1.0f / (2.0f * maf * (1.0f - maf));
+        m = (n1 * (double)a + n2 * b) / (double)n_keep;
+        cmu[e] = a != 0.f ? (float)(m / (double)a) : 0.f;
+    }
+    for (int c = 0; c < n_sketch + n_norm; ++c) {
+        float v = 0.f;
+        if (live) {
+            const double inv_s = 1.0 / (double)scale[c];
+            const double g = rd(PG, c) * inv_s, tt = 0.5 * rd(PT, c) * inv_s;
+            v = (float)((double)t * ((double)a * (g - 2.0 * tt) + b * tt - m * (csum[c] * inv_s)));
+        }
+        if (c < n_sketch) {
+            const float w1 = t * a * v, w2 = -t * v;
+            if (live) {
+                W1[(int64_t)e * n_sketch + c] = w1;
+                W2[(int64_t)e * n_sketch + c] = w2;
+            }
+            float m1 = live ? fabsf(w1) : 0.f, m2 = live ? fabsf(w2) : 0.f;
+            for (int off = 32; off; off >>= 1) {
+                m1 = fmaxf(m1, __shfl_xor(m1, off));
+                m2 = fmaxf(m2, __shfl_xor(m2, off));
+            }
+            if ((threadIdx.x & 63) == 0) {
+                atomicMax(&wmax1[c], __float_as_uint(m1));
+                atomicMax(&wmax2[c], __float_as_uint(m2));
+            }
+        } else {
+            double s2 = live ? (double)v * (double)v : 0.0;
+            for (int off = 32; off; off >>= 1) s2 += __shfl_xor(s2, off);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&norm_acc[c - n_sketch], s2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // mid 2: W -> fp16 operand image for GEMM 2 + rank-1 correction  corr[c] = sum_e mu_e * Wh[e][c]
 // Wfrag layout: [kb][part][tile][lane 64][8 halves]; lane = q*16 + c; element j <-> entry 32 kb + 8 q + j
 // ------------------------------------------------------------------------------------------------
@@ -631,7 +700,7 @@ __global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restr
 // in-order vector-memory queue.  MFMA u consumes crumb u of every dword: with the subnormal unpack the
 // accumulator of MFMA u carries the constant 4^(u&3) * 2^-24, removed once in the epilogue.
 // ------------------------------------------------------------------------------------------------
-template <int NTO, int PARTS, int IW, bool EXACT, bool MISSING>
+template <int NTO, int PARTS, int IW, bool EXACT, bool MISSING, int GV = 0>
 __global__ __launch_bounds__(256, 2) void gemm2_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                     const int32_t* __restrict__ rows32, int n_kb,
                                                     int kb_per_split, const float* __restrict__ fill,
@@ -720,10 +789,10 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const uint8_t* __restrict
                 for (int p = 0; p < 4; ++p) {
                     uint32_t src = (ug & 2) ? y[p] : x[p];
                     if (ug & 1) src >>= 8;
-                    f[0].u[p] = unpack<0, EXACT>(src);
-                    f[1].u[p] = unpack<1, EXACT>(src);
-                    f[2].u[p] = unpack<2, EXACT>(src);
-                    f[3].u[p] = unpack<3, EXACT>(src);
+                    f[0].u[p] = unpack<0, EXACT, GV>(src);
+                    f[1].u[p] = unpack<1, EXACT, GV>(src);
+                    f[2].u[p] = unpack<2, EXACT, GV>(src);
+                    f[3].u[p] = unpack<3, EXACT, GV>(src);
                 }
 #pragma unroll
                 for (int p = 0; p < PARTS; ++p)
@@ -1114,6 +1183,12 @@ struct pyrhe_engine {
         uint8_t* base; float* P; uint32_t* wmax; double* corr; double* normacc; float* mu; float* Wtmp; float* wscale;
         half8* wfrag; int32_t* rows32;
     } sets[2];
+    // dominance (RHE_DOM) extras, allocated on first use: one zeroed region (P2 | wmax2 | normacc2) + W2, cmu, zeros
+    uint8_t* dom_ws = nullptr;
+    size_t dom_zero_bytes = 0;
+    float *P2 = nullptr, *Wtmp2 = nullptr, *cmu = nullptr, *zcoef = nullptr;
+    uint32_t* wmax2 = nullptr;
+    double* normacc2 = nullptr;
     hipStream_t sA = nullptr, sB = nullptr;
     hipEvent_t evIn = nullptr, evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, evDoneA = nullptr, evDoneB = nullptr;
     uint64_t sub_counter = 0;     // sub-blocks enqueued so far (set = counter & 1)
@@ -1247,7 +1322,7 @@ extern "C" int pyrhe_engine_destroy(pyrhe_engine_t* e) {
     if (e->evIn) (void)hipEventDestroy(e->evIn);
     if (e->evDoneA) (void)hipEventDestroy(e->evDoneA);
     if (e->evDoneB) (void)hipEventDestroy(e->evDoneB);
-    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->partial);
+    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->partial); hipFree(e->dom_ws);
     delete e;
     return PYRHE_OK;
 }
@@ -1343,25 +1418,25 @@ struct ProfScope {
     }
 };
 
-template <int NTL, int PARTS, bool EXACT>
+template <int NTL, int PARTS, bool EXACT, int GV = 0>
 static void launch_gemm1(pyrhe_engine* e, const uint8_t* packed, const int32_t* rows, int n, const float* fill,
                          int n_steps, int sps, int splits, hipStream_t stream) {
     dim3 grid((n + 255) / 256, splits);
     const size_t lds = (size_t)2 * 2 * 8 * PARTS * NTL * 1024;   // [2 buffers][2 chunks][8 PARTS NTL fragments][1 KiB]
     if (fill)
-        gemm1_kernel<NTL, PARTS, EXACT, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_steps, sps, e->P, splits > 1);
+        gemm1_kernel<NTL, PARTS, EXACT, true, GV><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_steps, sps, e->P, splits > 1);
     else
-        gemm1_kernel<NTL, PARTS, EXACT, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_steps, sps, e->P, splits > 1);
+        gemm1_kernel<NTL, PARTS, EXACT, false, GV><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_steps, sps, e->P, splits > 1);
 }
 
-template <int NTO, int PARTS, int IW, bool EXACT>
+template <int NTO, int PARTS, int IW, bool EXACT, int GV = 0>
 static void launch_gemm2(pyrhe_engine* e, const uint8_t* packed, int n_kb, int kbps, int splits, const float* fill,
                          float* out, int mode, float* partial, hipStream_t stream) {
     dim3 grid((unsigned)((e->n_pad + 1024 * IW - 1) / (1024 * IW)), splits);
     if (fill)
-        gemm2_kernel<NTO, PARTS, IW, EXACT, true><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial);
+        gemm2_kernel<NTO, PARTS, IW, EXACT, true, GV><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial);
     else
-        gemm2_kernel<NTO, PARTS, IW, EXACT, false><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial);
+        gemm2_kernel<NTO, PARTS, IW, EXACT, false, GV><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial);
 }
 
 // out[i] += sum_s partial[s][i]   (K-split partial sketches; float4 granularity)
@@ -1382,10 +1457,11 @@ __global__ void add_norm_kernel(const double* __restrict__ src, double* __restri
     if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
 }
 
-extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
-                                         const int32_t* entries, const int64_t* offsets_host, int nbin,
-                                         const float* fill, float* out_sketch, double* out_norm,
-                                         int32_t* out_colsum, int accumulate, void* stream_) {
+// One implementation behind pyrhe_engine_sketch_block (additive sketches) and pyrhe_engine_sketch_block_dom
+// (additive + dominance sketches, RHE_DOM).
+static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows, const int32_t* entries,
+                       const int64_t* offsets_host, int nbin, const float* fill, float* out_sketch, double* out_norm,
+                       int32_t* out_colsum, int accumulate, float* out_dom, double* norm_dom, void* stream_) {
     if (!e || !packed || !offsets_host) return fail(PYRHE_EINVAL, "NULL argument");
     if (!e->rhs_set) return fail(PYRHE_ESTATE, "pyrhe_engine_set_rhs has not been called");
     if (nbin < 1) return fail(PYRHE_EINVAL, "nbin must be >= 1");
@@ -1402,11 +1478,18 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
     if (n_rows >= (1 << 24) || e->pitch >= (1 << 24) || (uint64_t)n_rows * (uint64_t)e->pitch >= (1ull << 32))
         return fail(PYRHE_EINVAL, "block of %lld rows x %lld bytes exceeds the 32-bit row offsets of one call; split it",
                     (long long)n_rows, (long long)e->pitch);
+    const bool dom = out_dom != nullptr || norm_dom != nullptr;
+    if (dom && ((e->n_sketch && !out_dom) || (e->n_norm && !norm_dom))) return fail(PYRHE_EINVAL, "dominance outputs incomplete");
     hipStream_t caller = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(e->device));
+    // int8 GEMM 2 (K = 64 SNPs per step, three int32 accumulator sets): correct (agrees with the fp16 hi+lo form to
+    // 4e-10 on sigma^2) but measured SLOWER at N=500k -- 40.4 ms vs 32.9 ms per pass: 468 registers pin it to one wave
+    // per SIMD and the 16x16 crumb transpose costs 240 v_perm/v_and per step.  Kept opt-in (PYRHE_G2_I8=1).
+    static const bool g2i8_env = getenv("PYRHE_G2_I8") && atoi(getenv("PYRHE_G2_I8")) != 0;
+    const bool g2i8 = g2i8_env && e->i8 && e->nto == 1 && e->n_sketch > 0 && !dom;
     // Serial mode (default): everything goes to the caller's stream, no events.  Pipelined mode: private streams A
     // (GEMM 1 + mid kernels) and B (GEMM 2), ordered against the caller's stream by events.
-    const bool piped = e->pipeline;
+    const bool piped = e->pipeline && !dom;
     if (!piped && e->pending) {      // leftovers of earlier pipelined calls: order them before this call
         HIPCHK(hipStreamWaitEvent(caller, e->evDoneA, 0));
         HIPCHK(hipStreamWaitEvent(caller, e->evDoneB, 0));
@@ -1423,15 +1506,150 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
     const int n_chunks = (int)(e->pitch / 64);
     const int ncol_p = 16 * e->ntl;
     const int64_t sk_stride = (int64_t)e->n_sketch * e->n_pad;
+    const float pscale = e->exact ? 1.0f : 16777216.0f;
+    const int kstep = g2i8 ? 64 : 32;
+
+    if (dom && !e->dom_ws) {
+        const size_t S = (size_t)e->sub_snps, nc = 16 * kMaxTiles;
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+        const size_t oP2 = carve(S * nc * sizeof(float) * (e->i8 ? 3 : 1));
+        const size_t oWm = carve(nc * sizeof(uint32_t));
+        const size_t oNa = carve(nc * sizeof(double));
+        e->dom_zero_bytes = off;
+        const size_t oW2 = carve(S * nc * sizeof(float));
+        const size_t oCm = carve(S * sizeof(float));
+        const size_t oZc = carve(S * sizeof(float));
+        HIPCHK(hipMalloc(&e->dom_ws, off));
+        HIPCHK(hipMemset(e->dom_ws, 0, off));
+        e->P2 = (float*)(e->dom_ws + oP2);
+        e->wmax2 = (uint32_t*)(e->dom_ws + oWm);
+        e->normacc2 = (double*)(e->dom_ws + oNa);
+        e->Wtmp2 = (float*)(e->dom_ws + oW2);
+        e->cmu = (float*)(e->dom_ws + oCm);
+        e->zcoef = (float*)(e->dom_ws + oZc);
+    }
+
+    // ---- GEMM 1 of one entry list, genotype view gv, into Pbuf (zeroed by the caller)
+    auto run_gemm1 = [&](int gv, const int32_t* rows, int n, float* Pbuf) {
+        const int gx = (n + 255) / 256;
+        const int n_steps = n_chunks / 2;                 // 512-sample steps (pitch is a multiple of 256 B)
+        int splits = (768 + gx - 1) / gx;
+        splits = std::max(1, std::min(splits, n_steps / 4 > 0 ? n_steps / 4 : 1));
+        int cps = (n_steps + splits - 1) / splits;        // steps per split, even (n_steps is even)
+        cps += cps & 1;
+        splits = (n_steps + cps - 1) / cps;
+        float* saveP = e->P;
+        e->P = Pbuf;
+        ProfScope ps(e, stream, 0);
+        dim3 grid(gx, splits);
+        const int ua = splits > 1;
+        if (e->i8) {
+            const size_t lds = (size_t)2 * 2 * 12 * e->ntl * 1024;
+#define G1I(NTL_, MISS_, GV_) gemm1_i8_kernel<NTL_, MISS_, GV_><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua)
+            if (gv == 0) { if (e->ntl == 1) { if (fill) G1I(1, true, 0); else G1I(1, false, 0); } else { if (fill) G1I(2, true, 0); else G1I(2, false, 0); } }
+            else         { if (e->ntl == 1) { if (fill) G1I(1, true, 1); else G1I(1, false, 1); } else { if (fill) G1I(2, true, 1); else G1I(2, false, 1); } }
+#undef G1I
+        } else {
+#define G1(NTL_, PARTS_, EX_, GV_) launch_gemm1<NTL_, PARTS_, EX_, GV_>(e, packed, rows, n, fill, n_steps, cps, splits, stream)
+            if (gv == 0) {
+                if (e->parts == 2) { if (e->ntl == 1) G1(1, 2, true, 0); else G1(2, 2, true, 0); }
+                else if (e->exact) { if (e->ntl == 1) G1(1, 1, true, 0); else G1(2, 1, true, 0); }
+                else { if (e->ntl == 1) G1(1, 1, false, 0); else G1(2, 1, false, 0); }
+            } else {
+                if (e->parts == 2) { if (e->ntl == 1) G1(1, 2, true, 1); else G1(2, 2, true, 1); }
+                else if (e->exact) { if (e->ntl == 1) G1(1, 1, true, 1); else G1(2, 1, true, 1); }
+                else { if (e->ntl == 1) G1(1, 1, false, 1); else G1(2, 1, false, 1); }
+            }
+#undef G1
+        }
+        e->P = saveP;
+    };
+
+    // ---- W (float) -> operand image + rank-1 correction, then GEMM 2 with genotype view gv into outp
+    auto run_gemm2 = [&](int gv, const float* Wsrc, const float* coef, const uint32_t* wmaxp, int n, int n_kb, float* outp,
+                         bool acc_now, int set) -> int {
+        {
+            ProfScope ps(e, stream, 1);
+            const int64_t threads = (int64_t)n_kb * e->parts * e->nto * 64;
+            const unsigned grid = (unsigned)((threads + 255) / 256);
+            if (g2i8) {
+                const int64_t th = (int64_t)n_kb * 3 * 64;
+                mid2_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, wmaxp, (int4v*)e->wfrag, e->corr, e->wscale);
+            } else if (e->parts == 2) mid2_kernel<2><<<grid, 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale);
+            else mid2_kernel<1><<<grid, 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale);
+        }
+        if (piped) {      // GEMM 2 goes to stream B, behind this sub-block's mid kernels on stream A
+            HIPCHK(hipEventRecord(e->evA[set], e->sA));
+            HIPCHK(hipStreamWaitEvent(sB2, e->evA[set], 0));
+        }
+        // 512 samples per wave (8-byte loads, one 128-B line per row per 16 lanes) when the accumulators fit; measured at
+        // N=500k: the single-rounding pass is fastest with 512-sample waves even at 1 wave/SIMD, the hi+lo pass with
+        // 256-sample waves at 2 waves/SIMD
+        int iw = (e->nto == 1 && e->parts == 1 && e->n_pad >= 2048 * 160) ? 2 : 1;
+        if (g2i8) iw = 1;
+        if (const char* ev = getenv("PYRHE_G2_IW")) iw = atoi(ev) == 2 && e->nto == 1 ? 2 : 1;
+        const int gx = (int)((e->n_pad + 1024 * iw - 1) / (1024 * iw));
+        int splits = gx >= 192 ? 1 : std::min(16, (512 + gx - 1) / gx);
+        if (const char* ev = getenv("PYRHE_G2_SPLITS")) splits = atoi(ev);
+        splits = std::max(splits, (n_kb + (g2i8 ? 255 : 511)) / (g2i8 ? 256 : 512));   // row list of a K range lives in LDS: <= 64 KiB
+        splits = std::max(1, std::min(splits, n_kb));
+        const int kbps = (n_kb + splits - 1) / splits;
+        splits = (n_kb + kbps - 1) / kbps;
+        int mode;
+        float* partial = nullptr;
+        if (splits > 1 && splits <= 16) {
+            // K splits write private partials, summed by one streaming kernel (no atomics)
+            const size_t need = (size_t)(splits - 1) * sk_stride * sizeof(float);
+            if (e->partial_bytes < need) {
+                if (e->partial) HIPCHK(hipFree(e->partial));
+                HIPCHK(hipMalloc(&e->partial, need));
+                e->partial_bytes = need;
+            }
+            partial = e->partial;
+            mode = acc_now ? 1 : 0;
+        } else if (splits > 1) {
+            if (!acc_now) HIPCHK(hipMemsetAsync(outp, 0, sk_stride * sizeof(float), sB2));
+            mode = 2;
+        } else {
+            mode = acc_now ? 1 : 0;
+        }
+        ProfScope ps(e, sB2, 2);
+#define G2(NTO_, PARTS_, IW_, EX_, GV_) launch_gemm2<NTO_, PARTS_, IW_, EX_, GV_>(e, packed, n_kb, kbps, splits, fill, outp, mode, partial, sB2)
+        if (g2i8) {
+            dim3 grid((unsigned)((e->n_pad + 1023) / 1024), splits);
+            const size_t lds = (size_t)kbps * 256;
+            if (fill) gemm2_i8_kernel<true><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, mode, partial);
+            else gemm2_i8_kernel<false><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, mode, partial);
+        } else if (gv == 0) {
+            if (e->parts == 2) { if (iw == 2) G2(1, 2, 2, true, 0); else if (e->nto == 1) G2(1, 2, 1, true, 0); else G2(2, 2, 1, true, 0); }
+            else if (e->exact) { if (iw == 2) G2(1, 1, 2, true, 0); else if (e->nto == 1) G2(1, 1, 1, true, 0); else G2(2, 1, 1, true, 0); }
+            else { if (iw == 2) G2(1, 1, 2, false, 0); else if (e->nto == 1) G2(1, 1, 1, false, 0); else G2(2, 1, 1, false, 0); }
+        } else {
+            if (e->parts == 2) { if (iw == 2) G2(1, 2, 2, true, 1); else if (e->nto == 1) G2(1, 2, 1, true, 1); else G2(2, 2, 1, true, 1); }
+            else if (e->exact) { if (iw == 2) G2(1, 1, 2, true, 1); else if (e->nto == 1) G2(1, 1, 1, true, 1); else G2(2, 1, 1, true, 1); }
+            else { if (iw == 2) G2(1, 1, 2, false, 1); else if (e->nto == 1) G2(1, 1, 1, false, 1); else G2(2, 1, 1, false, 1); }
+        }
+#undef G2
+        if (partial) {
+            const int64_t n4 = sk_stride / 4;
+            add_partials_kernel<<<2048, 256, 0, sB2>>>((float4*)outp, (const float4*)partial, splits - 1, n4);
+        }
+        return PYRHE_OK;
+    };
 
     for (int b = 0; b < nbin; ++b) {
         const int64_t n_b = offsets_host[b + 1] - offsets_host[b];
         float* outb = out_sketch ? out_sketch + b * sk_stride : nullptr;
         double* normb = out_norm ? out_norm + (int64_t)b * e->n_norm : nullptr;
+        float* outd = out_dom ? out_dom + b * sk_stride : nullptr;
+        double* normd = norm_dom ? norm_dom + (int64_t)b * e->n_norm : nullptr;
         if (n_b == 0) {
             if (!accumulate) {
                 if (outb) HIPCHK(hipMemsetAsync(outb, 0, sk_stride * sizeof(float), sB2));
                 if (normb && e->n_norm) HIPCHK(hipMemsetAsync(normb, 0, e->n_norm * sizeof(double), stream));
+                if (outd) HIPCHK(hipMemsetAsync(outd, 0, sk_stride * sizeof(float), sB2));
+                if (normd && e->n_norm) HIPCHK(hipMemsetAsync(normd, 0, e->n_norm * sizeof(double), stream));
             }
             continue;
         }
@@ -1439,123 +1657,50 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
         for (int64_t s0 = 0; s0 < n_b; s0 += e->sub_snps) {
             const int n = (int)std::min<int64_t>(e->sub_snps, n_b - s0);
             const int32_t* rows = entries + offsets_host[b] + s0;
-            // int8 GEMM 2 (K = 64 SNPs per step, three int32 accumulator sets): correct (agrees with the fp16 hi+lo form
-            // to 4e-10 on sigma^2) but measured SLOWER at N=500k -- 40.4 ms vs 32.9 ms per pass: 468 registers pin it to one
-            // wave per SIMD and the 16x16 crumb transpose costs 240 v_perm/v_and per step.  Kept opt-in (PYRHE_G2_I8=1).
-            static const bool g2i8_env = getenv("PYRHE_G2_I8") && atoi(getenv("PYRHE_G2_I8")) != 0;
-            const bool g2i8 = g2i8_env && e->i8 && e->nto == 1 && e->n_sketch > 0;
-            const int kstep = g2i8 ? 64 : 32;
             const int n32 = (n + kstep - 1) / kstep * kstep;
             const int n_kb = n32 / kstep;
             const int set = (int)(e->sub_counter & 1);
             e->use_set(set);
             if (piped && e->sub_counter >= 2) HIPCHK(hipStreamWaitEvent(e->sA, e->evB[set], 0));   // GEMM 2 of sub-block g-2 is done with this set
             e->sub_counter++;
+            const bool acc_now = accumulate || !first;
             HIPCHK(hipMemsetAsync(e->ws, 0, e->zero_bytes, stream));
             pad_rows_kernel<<<(n32 + 255) / 256, 256, 0, stream>>>(rows, n, n32, e->rows32);
-            // ---- GEMM 1
-            {
-                const int gx = (n + 255) / 256;
-                const int n_steps = n_chunks / 2;                 // 512-sample steps (pitch is a multiple of 256 B)
-                int splits = (768 + gx - 1) / gx;
-                splits = std::max(1, std::min(splits, n_steps / 4 > 0 ? n_steps / 4 : 1));
-                int cps = (n_steps + splits - 1) / splits;        // steps per split, even (n_steps is even)
-                cps += cps & 1;
-                splits = (n_steps + cps - 1) / cps;
-                ProfScope ps(e, stream, 0);
-#define G1(NTL_, PARTS_, EX_) launch_gemm1<NTL_, PARTS_, EX_>(e, packed, rows, n, fill, n_steps, cps, splits, stream)
-                if (e->i8) {
-                    dim3 grid((n + 255) / 256, splits);
-                    const size_t lds = (size_t)2 * 2 * 12 * e->ntl * 1024;
-                    const int ua = splits > 1;
-                    if (e->ntl == 1) {
-                        if (fill) gemm1_i8_kernel<1, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)e->P, ua);
-                        else gemm1_i8_kernel<1, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)e->P, ua);
-                    } else {
-                        if (fill) gemm1_i8_kernel<2, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)e->P, ua);
-                        else gemm1_i8_kernel<2, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)e->P, ua);
-                    }
-                } else if (e->parts == 2) { if (e->ntl == 1) G1(1, 2, true); else G1(2, 2, true); }
-                else if (e->exact) { if (e->ntl == 1) G1(1, 1, true); else G1(2, 1, true); }
-                else { if (e->ntl == 1) G1(1, 1, false); else G1(2, 1, false); }
-#undef G1
-            }
-            // ---- mid
+            run_gemm1(0, rows, n, e->P);
             {
                 ProfScope ps(e, stream, 1);
-                mid1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->exact ? 1.0f : 16777216.0f, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
+                mid1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
                                                                  (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->normacc,
                                                                  out_colsum ? out_colsum + offsets_host[b] + s0 : nullptr);
-                if (e->n_sketch) {
-                    const int64_t threads = (int64_t)n_kb * e->parts * e->nto * 64;
-                    const unsigned grid = (unsigned)((threads + 255) / 256);
-                    if (g2i8) {
-                        const int64_t th = (int64_t)n_kb * 3 * 64;
-                        mid2_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(e->Wtmp, e->mu, n, n_kb, e->n_sketch, e->wmax, (int4v*)e->wfrag, e->corr, e->wscale);
-                    } else if (e->parts == 2) mid2_kernel<2><<<grid, 256, 0, stream>>>(e->Wtmp, e->mu, n, n_kb, e->n_sketch, e->nto, e->wmax, e->wfrag, e->corr, e->wscale);
-                    else mid2_kernel<1><<<grid, 256, 0, stream>>>(e->Wtmp, e->mu, n, n_kb, e->n_sketch, e->nto, e->wmax, e->wfrag, e->corr, e->wscale);
-                }
-                if (e->n_norm) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc, normb, e->n_norm, accumulate || !first);
+                if (e->n_norm) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc, normb, e->n_norm, acc_now);
             }
-            // ---- GEMM 2 on stream B, behind this sub-block's mid kernels
-            if (piped) {
+            if (!e->n_sketch && piped) {
                 HIPCHK(hipEventRecord(e->evA[set], e->sA));
                 HIPCHK(hipStreamWaitEvent(sB2, e->evA[set], 0));
             }
             if (e->n_sketch) {
-                // 512 samples per wave (8-byte loads, 128 B per row per 16 lanes) when the accumulators fit and the
-                // grid still fills the chip; otherwise 256 samples per wave
-                // the grid must give every SIMD >= 2 waves (one wave issues a VALU op only every 4 cycles, two
-                // interleave at 2): 512-sample waves only when that still leaves >= 512 workgroups
-                // (measured at N=500k: one fp16 pass is faster with 512-sample waves even at 1 wave/SIMD, the hi+lo
-                // mode with 256-sample waves at 2 waves/SIMD)
-                int iw = (e->nto == 1 && e->parts == 1 && e->n_pad >= 2048 * 160) ? 2 : 1;
-                if (g2i8) iw = 1;
-                if (const char* ev = getenv("PYRHE_G2_IW")) iw = atoi(ev) == 2 && e->nto == 1 ? 2 : 1;
-                const int gx = (int)((e->n_pad + 1024 * iw - 1) / (1024 * iw));
-                int splits = gx >= 192 ? 1 : std::min(16, (512 + gx - 1) / gx);
-                if (const char* ev = getenv("PYRHE_G2_SPLITS")) splits = atoi(ev);
-                splits = std::max(splits, (n_kb + (g2i8 ? 255 : 511)) / (g2i8 ? 256 : 512));   // row list of a K range lives in LDS: <= 64 KiB
-                splits = std::max(1, std::min(splits, n_kb));
-                const int kbps = (n_kb + splits - 1) / splits;
-                splits = (n_kb + kbps - 1) / kbps;
-                int mode;
-                const bool acc_now = accumulate || !first;
-                float* partial = nullptr;
-                if (splits > 1 && splits <= 16) {
-                    // big outputs: K splits write private partials, summed by one streaming kernel (no atomics)
-                    const size_t need = (size_t)(splits - 1) * sk_stride * sizeof(float);
-                    if (e->partial_bytes < need) {
-                        if (e->partial) HIPCHK(hipFree(e->partial));
-                        HIPCHK(hipMalloc(&e->partial, need));
-                        e->partial_bytes = need;
-                    }
-                    partial = e->partial;
-                    mode = acc_now ? 1 : 0;
-                } else if (splits > 1) {
-                    if (!acc_now) HIPCHK(hipMemsetAsync(outb, 0, sk_stride * sizeof(float), sB2));
-                    mode = 2;
-                } else {
-                    mode = acc_now ? 1 : 0;
+                const int rc = run_gemm2(0, e->Wtmp, e->mu, e->wmax, n, n_kb, outb, acc_now, set);
+                if (rc) return rc;
+            }
+            if (dom) {
+                // ---- dominance: second GEMM 1 with the 2*[g==2] view, then two GEMM 2 launches into out_dom
+                HIPCHK(hipMemsetAsync(e->dom_ws, 0, e->dom_zero_bytes, stream));
+                run_gemm1(1, rows, n, e->P2);
+                HIPCHK(hipMemsetAsync(e->corr, 0, 16 * kMaxTiles * sizeof(double), stream));
+                HIPCHK(hipMemsetAsync(e->wmax, 0, 16 * kMaxTiles * sizeof(uint32_t), stream));
+                {
+                    ProfScope ps(e, stream, 1);
+                    mid_dom1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->P2, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale,
+                                                                         e->csum, (float)e->n_keep, e->cmu, e->Wtmp, e->Wtmp2, e->wmax, e->wmax2,
+                                                                         e->normacc2);
+                    if (e->n_norm) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc2, normd, e->n_norm, acc_now);
                 }
-                ProfScope ps(e, sB2, 2);
-#define G2(NTO_, PARTS_, IW_, EX_) launch_gemm2<NTO_, PARTS_, IW_, EX_>(e, packed, n_kb, kbps, splits, fill, outb, mode, partial, sB2)
-                if (g2i8) {
-                    dim3 grid((unsigned)((e->n_pad + 1023) / 1024), splits);
-                    const size_t lds = (size_t)kbps * 256;
-                    if (fill) gemm2_i8_kernel<true><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outb, mode, partial);
-                    else gemm2_i8_kernel<false><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outb, mode, partial);
-                } else if (e->parts == 2) {
-                    if (iw == 2) G2(1, 2, 2, true); else if (e->nto == 1) G2(1, 2, 1, true); else G2(2, 2, 1, true);
-                } else if (e->exact) {
-                    if (iw == 2) G2(1, 1, 2, true); else if (e->nto == 1) G2(1, 1, 1, true); else G2(2, 1, 1, true);
-                } else {
-                    if (iw == 2) G2(1, 1, 2, false); else if (e->nto == 1) G2(1, 1, 1, false); else G2(2, 1, 1, false);
-                }
-#undef G2
-                if (partial) {
-                    const int64_t n4 = sk_stride / 4;
-                    add_partials_kernel<<<2048, 256, 0, sB2>>>((float4*)outb, (const float4*)partial, splits - 1, n4);
+                if (e->n_sketch) {
+                    int rc = run_gemm2(0, e->Wtmp, e->cmu, e->wmax, n, n_kb, outd, acc_now, set);
+                    if (rc) return rc;
+                    HIPCHK(hipMemsetAsync(e->corr, 0, 16 * kMaxTiles * sizeof(double), stream));
+                    rc = run_gemm2(1, e->Wtmp2, e->zcoef, e->wmax2, n, n_kb, outd, true, set);
+                    if (rc) return rc;
                 }
             }
             if (piped) HIPCHK(hipEventRecord(e->evB[set], sB2));
@@ -1574,6 +1719,24 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
         }
     }
     return PYRHE_OK;
+}
+
+extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
+                                         const int32_t* entries, const int64_t* offsets_host, int nbin,
+                                         const float* fill, float* out_sketch, double* out_norm,
+                                         int32_t* out_colsum, int accumulate, void* stream_) {
+    return sketch_impl(e, packed, n_rows, entries, offsets_host, nbin, fill, out_sketch, out_norm, out_colsum, accumulate,
+                       nullptr, nullptr, stream_);
+}
+
+extern "C" int pyrhe_engine_sketch_block_dom(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
+                                             const int32_t* entries, const int64_t* offsets_host, int nbin,
+                                             const float* fill, float* out_sketch, double* out_norm,
+                                             float* out_sketch_dom, double* out_norm_dom, int accumulate,
+                                             void* stream_) {
+    if (!out_sketch_dom && !out_norm_dom) return fail(PYRHE_EINVAL, "dominance outputs are NULL");
+    return sketch_impl(e, packed, n_rows, entries, offsets_host, nbin, fill, out_sketch, out_norm, nullptr, accumulate,
+                       out_sketch_dom, out_norm_dom, stream_);
 }
 
 extern "C" int pyrhe_engine_set_async(pyrhe_engine_t* e, int enable) {

@@ -35,6 +35,7 @@ SYMBOLS = {
     "pyrhe_engine_destroy": (_i32, [_vp]),
     "pyrhe_engine_set_rhs": (_i32, [_vp, _vp, C.POINTER(C.c_int32), _i32, _vp, _vp]),
     "pyrhe_engine_sketch_block": (_i32, [_vp, _vp, _i64, _vp, C.POINTER(_i64), _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "pyrhe_engine_sketch_block_dom": (_i32, [_vp, _vp, _i64, _vp, C.POINTER(_i64), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "pyrhe_engine_block_stats": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "pyrhe_engine_set_async": (_i32, [_vp, _i32]),
     "pyrhe_engine_join": (_i32, [_vp, _vp]),
@@ -230,6 +231,30 @@ class SketchEngine:
                                                       1 if accumulate else 0, _stream_ptr(self.device)),
                    "pyrhe_engine_sketch_block")
         return out_sketch, out_norm, colsum
+
+    def sketch_block_dom(self, packed: torch.Tensor, entries: torch.Tensor, offsets: Sequence[int], *,
+                         fill: Optional[torch.Tensor] = None, out_sketch=None, out_norm=None, out_sketch_dom=None,
+                         out_norm_dom=None, accumulate: bool = False):
+        """Additive + dominance (RHE_DOM) sketches of one block; returns the four output tensors."""
+        nbin = len(offsets) - 1
+        assert packed.dtype == torch.uint8 and packed.is_contiguous() and packed.shape[1] == self.pitch
+
+        def _mk(t, shape, dtype):
+            if t is None:
+                assert not accumulate
+                return torch.empty(shape, dtype=dtype, device=self.device)
+            return t
+        out_sketch = _mk(out_sketch, (nbin, self.n_sketch, self.n_pad), torch.float32)
+        out_sketch_dom = _mk(out_sketch_dom, (nbin, self.n_sketch, self.n_pad), torch.float32)
+        out_norm = _mk(out_norm, (nbin, max(self.n_norm, 1)), torch.float64)
+        out_norm_dom = _mk(out_norm_dom, (nbin, max(self.n_norm, 1)), torch.float64)
+        offs = (C.c_int64 * (nbin + 1))(*[int(o) for o in offsets])
+        with torch.cuda.device(self.device):
+            _check(self.lib.pyrhe_engine_sketch_block_dom(self._h, _ptr(packed), packed.shape[0], _ptr(entries), offs, nbin,
+                                                          _ptr(fill), _ptr(out_sketch), _ptr(out_norm), _ptr(out_sketch_dom),
+                                                          _ptr(out_norm_dom), 1 if accumulate else 0, _stream_ptr(self.device)),
+                   "pyrhe_engine_sketch_block_dom")
+        return out_sketch, out_norm, out_sketch_dom, out_norm_dom
 
     def set_async(self, enable: bool):
         """Defer the per-call join: consecutive blocks then overlap (GEMM 1 of block j+1 beside GEMM 2 of block j)."""

@@ -259,6 +259,58 @@ class StreamingRHE(RHE):
     streaming = True
 
 
+class RHE_DOM(Base):
+    """Additive + dominance components per bin (``pyrhe/src/models/rhe_dom/rhe_dom.py``): estimates 0..nbin-1 use the
+    standardized allele counts, estimates nbin..2nbin-1 the dominance encoding (0, 2p, 4p-2) scaled by 1/(2p(1-p))."""
+
+    def get_num_estimates(self):
+        return self.num_bin * 2
+
+    def get_M_last_row(self):
+        return np.concatenate([self.len_bin, self.len_bin])
+
+    def _make_runner(self) -> SketchRunner:
+        return SketchRunner(self.engine, self.geno_dev, self.plan, self.local_blocks, n_orig=self.num_indv_original,
+                            missing_indv=self.missing_indv, Z=self.all_zb, cov=self.cov_matrix, impute=self.geno_impute_methods,
+                            seed=self.seed, streaming=self.streaming, compat=self.compat, recompute_pass2=self.recompute_pass2,
+                            rng_prefix_draws=self._rng_prefix, dom=True)
+
+    def run(self, method):
+        log = self.log._log
+        sigma_jack, sigma_total = self.estimate(method=method)
+        sig_errs = self.estimate_error(sigma_jack)
+        ne = self.num_estimates
+        log("Variance components: ")
+        for i, v in enumerate(sigma_total):
+            if i == len(sigma_total) - 1:
+                log(f"Sigma^2_e : {v}  SE : {sig_errs[i]}")
+            else:
+                log(f"Sigma^2_g[{i}] : {v}  SE : {sig_errs[i]}")
+        h2_jack, h2_total = est.h2_nonoverlapping(sigma_jack, sigma_total, ne)
+        h2_errs = self.estimate_error(h2_jack)
+        log("*****")
+        log("Heritabilities:")
+        for i, v in enumerate(h2_total):
+            if i == len(h2_total) - 1:
+                log(f"Total h2 : {v} SE: {h2_errs[i]}")
+            else:
+                log(f"h2_g[{i}] : {v} : {h2_errs[i]}")
+        log("*****")
+        log("Enrichments: ")
+        enr_jack, enr_total = est.enrichment(h2_jack, h2_total, self.M, ne)
+        enr_errs = self.estimate_error(enr_jack)
+        for i, v in enumerate(enr_total):
+            log(f"Enrichment g[{i}] : {v} SE : {enr_errs[i]}")
+        self.sigma_est_jackknife = sigma_jack
+        return {"sigma_ests_total": sigma_total, "sig_errs": sig_errs, "h2_total": h2_total, "h2_errs": h2_errs,
+                "enrichment_total": enr_total, "enrichment_errs": enr_errs}
+
+
+class StreamingRHE_DOM(RHE_DOM):
+    """``pyrhe/src/models/rhe_dom/streaming_rhe_dom.py`` semantics (one-worker streaming)."""
+    streaming = True
+
+
 class GENIE(Base):
     """Gene-environment model (``pyrhe/src/models/genie/genie.py``): G, G+GxE or G+GxE+NxE with ONE environment
     column named ``env``.  Non-streaming semantics, including the reference's treatment of the last estimate of

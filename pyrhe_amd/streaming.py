@@ -109,7 +109,7 @@ class SketchRunner:
                  n_orig: int, missing_indv: Sequence[int], Z: np.ndarray, cov: Optional[np.ndarray] = None,
                  env: Optional[np.ndarray] = None, genie_model: Optional[str] = None,
                  impute: str = "binary", seed: int = 0, streaming: bool = True, compat: str = "reference",
-                 recompute_pass2: bool = False, rng_prefix_draws: int = 0, group=None):
+                 recompute_pass2: bool = False, rng_prefix_draws: int = 0, group=None, dom: bool = False):
         self.engs = list(engines) if isinstance(engines, (list, tuple)) else [engines]
         self.eng = self.engs[0]
         self.geno = geno
@@ -145,7 +145,10 @@ class SketchRunner:
         nb = plan.n_bin
         self.n_gxe = nb if genie_model in ("G+GxE", "G+GxE+NxE") else 0
         self.n_nxe = 1 if genie_model == "G+GxE+NxE" else 0
-        self.n_est = nb + self.n_gxe + self.n_nxe
+        self.dom = bool(dom)          # RHE_DOM: a dominance estimate per bin after the additive ones (rhe_dom.py:7-13)
+        if self.dom and genie_model is not None:
+            raise ValueError("dominance and GENIE terms are separate models")
+        self.n_est = 2 * nb if self.dom else nb + self.n_gxe + self.n_nxe
         # Reference quirk (base.py:467,472-481): the NON-streaming GENIE treats its LAST estimate as the
         # heteroscedastic-noise term for every genie_model (GENIE sets num_env = 1, genie.py:18), so for "G+GxE" the
         # whole-data slot of the last GxE bin is overwritten by the N x E sketch.  ("G" raises IndexError there and
@@ -298,8 +301,13 @@ class SketchRunner:
                     fill = self._fill_for_block(j, u)
                     fills.append(fill)
                 for p in range(self.n_pass):
-                    self.engs[p].sketch_block(self._block_rows(j), ent, offs, fill=fill, out_sketch=out_sk[p][jl],
-                                              out_norm=out_norm[p][jl], accumulate=False)
+                    if self.dom:
+                        self.engs[p].sketch_block_dom(self._block_rows(j), ent, offs, fill=fill, out_sketch=out_sk[p][jl],
+                                                      out_norm=out_norm[p][jl], out_sketch_dom=self.blocks_skd[p][jl],
+                                                      out_norm_dom=self.blocks_nmd[p][jl], accumulate=False)
+                    else:
+                        self.engs[p].sketch_block(self._block_rows(j), ent, offs, fill=fill, out_sketch=out_sk[p][jl],
+                                                  out_norm=out_norm[p][jl], accumulate=False)
         finally:
             for eng in pipelined:
                 eng.join()
@@ -329,20 +337,27 @@ class SketchRunner:
         dev = self.device
         self.blocks_sk = [torch.empty((jl, nb, ns, self.n_pad), dtype=torch.float32, device=dev) for ns, _ in self.pass_shapes]
         self.blocks_nm = [torch.zeros((max(jl, 1), nb, nn), dtype=torch.float64, device=dev) for _, nn in self.pass_shapes]
+        self.blocks_skd = [torch.empty_like(b) for b in self.blocks_sk] if self.dom else None
+        self.blocks_nmd = [torch.zeros_like(b) for b in self.blocks_nm] if self.dom else None
 
     # ---- estimate-level views of one block's (or the total's) engine outputs ----------------------
     def _group(self, sk_list, name):
         p, c0 = self.loc[name]
         return sk_list[p][:, c0:c0 + self.k]
 
-    def _block_estimates(self, sk_list, nm_list):
+    def _block_estimates(self, sk_list, nm_list, skd_list=None, nmd_list=None):
         """A = XXz, C = XXUz ``[ne_g, k, n_pad]`` and r = yXXy ``[ne_g]`` of the genotype-derived estimates (G bins,
-        then G x E bins) from engine outputs of one block; float64."""
+        then dominance bins or G x E bins) from engine outputs of one block; float64."""
         f64 = torch.float64
         A = self._group(sk_list, "Z").to(f64)
         C = self._group(sk_list, "UZ").to(f64) if self.cov is not None else None
         py, cy = self.loc["y"]
         r = nm_list[py][:, cy]
+        if self.dom:
+            A = torch.cat([A, self._group(skd_list, "Z").to(f64)], dim=0)
+            if C is not None:
+                C = torch.cat([C, self._group(skd_list, "UZ").to(f64)], dim=0)
+            r = torch.cat([r, nmd_list[py][:, cy]], dim=0)
         if self.n_gxe:
             e = self.env_pad
             # elem_mul(X, env) then float32 GEMVs in the reference (streaming_genie.py:39-41): X_e X_e^T z = e.(X X^T (e.z))
@@ -375,7 +390,7 @@ class SketchRunner:
         plan, k = self.plan, self.k
         jn, jl, dev = plan.n_jack, self.j1 - self.j0, self.device
         self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0)
-        ne_g = plan.n_bin + self.n_gxe
+        ne_g = 2 * plan.n_bin if self.dom else plan.n_bin + self.n_gxe
         f64 = torch.float64
         use_cov = self.cov is not None
         q4 = use_cov and self.streaming and self.compat == "reference"
@@ -386,7 +401,11 @@ class SketchRunner:
             # U applied to the total (float32 rounding order differs from per-block application at the 1e-7 level).
             tot_sk = [b.sum(dim=0, dtype=f64) if jl else torch.zeros(b.shape[1:], dtype=f64, device=dev) for b in self.blocks_sk]
             tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
-            tot_A, tot_C, tot_r = self._block_estimates(tot_sk, tot_nm)
+            tot_skd = tot_nmd = None
+            if self.dom:
+                tot_skd = [b.sum(dim=0, dtype=f64) if jl else torch.zeros(b.shape[1:], dtype=f64, device=dev) for b in self.blocks_skd]
+                tot_nmd = [b[:jl].sum(dim=0) for b in self.blocks_nmd]
+            tot_A, tot_C, tot_r = self._block_estimates(tot_sk, tot_nm, tot_skd, tot_nmd)
             tot_A, tot_r = tot_A.contiguous(), tot_r.clone()
             tot_C = tot_C.contiguous() if use_cov else None
             D_tot = self._apply_U(tot_A, f32=True) if use_cov else None
@@ -397,7 +416,7 @@ class SketchRunner:
             D_tot = torch.zeros_like(tot_A)
             wsum = torch.zeros_like(tot_A) if self.world > 1 else None
             for jl_i in range(jl):
-                A, C, r = self._block_estimates([b[jl_i] for b in self.blocks_sk], [b[jl_i] for b in self.blocks_nm])
+                A, C, r = self._block_estimates(*self._stored_block(jl_i))
                 tot_A += A
                 tot_r += r
                 tot_C += C
@@ -428,7 +447,7 @@ class SketchRunner:
         M = np.zeros((jn + 1, ne), np.int64)
 
         def row(c):
-            parts = [c] + ([c] if self.n_gxe else []) + ([np.ones(1, np.int64)] if self.n_nxe else [])
+            parts = [c] + ([c] if (self.n_gxe or self.dom) else []) + ([np.ones(1, np.int64)] if self.n_nxe else [])
             return np.concatenate(parts)
         last = row(plan.len_bin)
         M[jn] = last
@@ -468,14 +487,14 @@ class SketchRunner:
         local = []
         for jl_i, j in enumerate(range(self.j0, self.j1)):
             if self.recompute_pass2:
-                sk_l, nm_l = self._resketch(j)
+                stored = self._resketch(j)
             else:
-                sk_l, nm_l = [b[jl_i] for b in self.blocks_sk], [b[jl_i] for b in self.blocks_nm]
+                stored = self._stored_block(jl_i)
             slot = jn if (jn == 1 and j == 0) else j          # base.py:654-655
             if slot == jn:
                 T, q = self._system(*with_nxe(tot_A, tot_C, D_tot, tot_r), M[jn], yy)
             else:
-                A, C, r = self._block_estimates(sk_l, nm_l)
+                A, C, r = self._block_estimates(*stored)
                 D = None
                 if use_cov:
                     D = D_tot - self._apply_U(A, f32=True)      # streaming_rhe.py:35-36
@@ -492,10 +511,19 @@ class SketchRunner:
         qs = np.stack([t[2] for t in local] + [q_tot])
         return Systems(Ts, qs, M)
 
+    def _stored_block(self, jl_i: int):
+        sk, nm = [b[jl_i] for b in self.blocks_sk], [b[jl_i] for b in self.blocks_nm]
+        if self.dom:
+            return sk, nm, [b[jl_i] for b in self.blocks_skd], [b[jl_i] for b in self.blocks_nmd]
+        return sk, nm, None, None
+
     def _resketch(self, j: int):
         ent, offs = self._entries(j)
+        if self.dom:
+            outs = [self.engs[p].sketch_block_dom(self._block_rows(j), ent, offs) for p in range(self.n_pass)]
+            return [o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], [o[3] for o in outs]
         outs = [self.engs[p].sketch_block(self._block_rows(j), ent, offs) for p in range(self.n_pass)]
-        return [o[0] for o in outs], [o[1] for o in outs]
+        return [o[0] for o in outs], [o[1] for o in outs], None, None
 
     def _allreduce(self, t: torch.Tensor):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

@@ -8,7 +8,6 @@ Deliberate, documented deviations:
   * ``--num_workers`` is accepted and ignored: parallelism is one process per GPU
     (``python -m torch.distributed.run --nproc-per-node N run_rhe.py ...``), blocks sharded across ranks;
   * new: ``--precision {f16x2,f16,f16e}``, ``--compat {reference,fixed}``, ``--recompute_pass2``;
-  * ``--model rhe_dom`` is not built yet.
 """
 import argparse
 import configparser
@@ -80,7 +79,7 @@ def main(args):
     import torch
     import torch.distributed as dist
     from pyrhe_amd.logger import Logger
-    from pyrhe_amd.models import GENIE, RHE, StreamingGENIE, StreamingRHE
+    from pyrhe_amd.models import GENIE, RHE, RHE_DOM, StreamingGENIE, StreamingRHE, StreamingRHE_DOM
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -118,7 +117,7 @@ def main(args):
         params.update(env_file=args.env, genie_model=args.genie_model)
         model = (StreamingGENIE if args.streaming else GENIE)(**params)
     elif args.model == "rhe_dom":
-        raise NotImplementedError("RHE_DOM is not part of this build yet (dominance encoding = SURVEY 8f next-3)")
+        model = (StreamingRHE_DOM if args.streaming else RHE_DOM)(**params)
     else:
         raise ValueError("Unsupported Model")
     results, runtime = {}, 0.0

@@ -152,3 +152,25 @@ def test_cli_end_to_end(tmp_path):
     assert re.search(r"Sigma\^2_e : ([-\d.e]+)  SE : ([-\d.e]+)", text)
     assert re.search(r"Total h2 : ([-\d.e]+) SE: ([-\d.e]+)", text)
     assert "PyRHE (v1.0.0)" in text and re.search(r"Runtime:  [\d.]+", text)
+
+
+@pytest.mark.parametrize("name", ["rhe_dom_2bin", "rhe_dom_cov"])
+@pytest.mark.parametrize("precision", ["i8x3", "f16x2"])
+def test_rhe_dom_matches_reference(name, precision, tmp_path):
+    """RHE_DOM: additive + dominance estimate per bin through pyrhe_engine_sketch_block_dom; 1e-5 on every reported number
+    (vector-level: relative to the largest entry of each reported vector, see test_genie_matches_reference)."""
+    from tests.helpers import RESULT_KEYS_GENIE
+    z = load_golden(name)
+    m, log = _run_model(z, tmp_path, "RHE_DOM", precision=precision)
+    n0 = len(log.msgs)
+    res = m(trait=0)
+    assert np.array_equal(m.M, z["ref_t0_M"])
+    Tref = z["ref_t0_T"]
+    assert np.abs(m.systems.T - Tref).max() <= 3e-6 * np.abs(Tref).max()
+    for k in RESULT_KEYS_GENIE:
+        r = z["ref_t0_res_" + k]
+        assert np.abs(np.asarray(res[k], float) - r).max() <= 1e-5 * max(np.abs(r).max(), 1e-3), k
+    ref_lines = str(z["ref_t0_log"]).splitlines()
+    got_lines = "".join(log.msgs[n0:]).splitlines()
+    strip = lambda ls: [re.sub(r"-?\d+\.\d+(e-?\d+)?|nan", "#", l) for l in ls]
+    assert strip(got_lines) == strip(ref_lines)
