@@ -1534,7 +1534,8 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     auto run_gemm1 = [&](int gv, const int32_t* rows, int n, float* Pbuf) {
         const int gx = (n + 255) / 256;
         const int n_steps = n_chunks / 2;                 // 512-sample steps (pitch is a multiple of 256 B)
-        int splits = (768 + gx - 1) / gx;
+        static const int g1_wgs = getenv("PYRHE_G1_WGS") ? atoi(getenv("PYRHE_G1_WGS")) : 1536;   // target workgroups per launch
+        int splits = (g1_wgs + gx - 1) / gx;
         splits = std::max(1, std::min(splits, n_steps / 4 > 0 ? n_steps / 4 : 1));
         int cps = (n_steps + splits - 1) / splits;        // steps per split, even (n_steps is even)
         cps += cps & 1;
