@@ -143,6 +143,13 @@ int pyrhe_engine_block_stats(pyrhe_engine_t* e, const uint8_t* packed, int64_t n
                              int32_t* out_sum, int32_t* out_nmiss, void* stream);
 
 /*
+ * out[i] = sum_{j < n_blocks} (double) blocks[j * block_stride + i], i < n: the float64 aggregate over per-block float32
+ * sketches (StreamingBase.aggregate, pyrhe/src/base/base_streaming.py:21-32; Base.aggregate, base.py:468-471) as one
+ * streaming pass.  blocks / out: device; n and block_stride multiples of 4.   Asynchronous on `stream`.
+ */
+int pyrhe_sum_blocks(const float* blocks, int n_blocks, int64_t block_stride, int64_t n, double* out, void* stream);
+
+/*
  * Decode rows to dense float32 [n_rows][n_pad] (count of allele 2, NaN = missing): the bit-exact
  * decode contract of bed_reader.read + the reference's flip (base.py:338-356).  Test/diagnostic entry
  * point; independent of any engine.   Asynchronous on `stream`.

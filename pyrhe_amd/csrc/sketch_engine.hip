@@ -529,49 +529,86 @@ __global__ __launch_bounds__(256) void gemm1_i8_kernel(const uint8_t* __restrict
 // ------------------------------------------------------------------------------------------------
 // mid 1: per entry statistics, V = X^T R, norm accumulation, W = D V (float32) + column maxima
 // ------------------------------------------------------------------------------------------------
-__global__ void mid1_kernel(const float* __restrict__ P, float pscale, int i8, int n_entries, int ncol_p, int n_sketch, int n_norm,
-                            const float* __restrict__ scale, const double* __restrict__ csum, float n_keep,
-                            float* __restrict__ mu_out, float* __restrict__ Wtmp,
-                            uint32_t* __restrict__ wmax_bits, double* __restrict__ norm_acc,
-                            int32_t* __restrict__ colsum_out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void mid1_kernel(const float* __restrict__ P, float pscale, int i8, int n_entries, int ncol_p,
+                                                   int n_sketch, int n_norm, const float* __restrict__ scale,
+                                                   const double* __restrict__ csum, float n_keep, float* __restrict__ mu_out,
+                                                   float* __restrict__ Wtmp, uint32_t* __restrict__ wmax_bits,
+                                                   double* __restrict__ norm_acc, int32_t* __restrict__ colsum_out) {
+    // workgroup = 64 entries; thread (c16, el): column c16 of a 16-column tile, entries el, el+16, el+32, el+48.
+    // Consecutive lanes read consecutive columns of one entry (coalesced); column maxima / norm sums are kept in
+    // registers over the 4 entries, folded over the wave by 2 shuffles and over the 4 waves through LDS.
+    __shared__ float s_mu[64], s_d[64];
+    __shared__ float s_max[4][16];
+    __shared__ double s_nrm[4][16];
+    const int c16 = threadIdx.x & 15, el = threadIdx.x >> 4, wave = threadIdx.x >> 6;
     const int ones = n_sketch + n_norm;
-    float mu = 0.f, d = 0.f;
-    const bool live = e < n_entries;
-    if (live) {
-        // exact integer (< 2^24); float P carries 1/pscale (2^-24 with the subnormal unpack); int8 mode: limb 0 as int32
-        const float sum = i8 ? (float)reinterpret_cast<const int*>(P)[(int64_t)e * 3 * ncol_p + ones]
-                             : P[(int64_t)e * ncol_p + ones] * pscale;
-        // float32, the reference's operation order (base.py:292-293): mean; 1/sqrt(mean*(1-0.5*mean))
-        mu = sum / n_keep;
-        d = 1.0f / sqrtf(mu * (1.0f - 0.5f * mu));
-        mu_out[e] = mu;
-        if (colsum_out) colsum_out[e] = (int32_t)sum;
+    const int ebase = blockIdx.x * 64;
+    if (threadIdx.x < 64) {
+        const int e = ebase + threadIdx.x;
+        float mu = 0.f, d = 0.f;
+        if (e < n_entries) {
+            // exact integer (< 2^24); float P carries 1/pscale (2^-24 with the subnormal unpack); int8 mode: limb 0 as int32
+            const float sum = i8 ? (float)reinterpret_cast<const int*>(P)[(int64_t)e * 3 * ncol_p + ones]
+                                 : P[(int64_t)e * ncol_p + ones] * pscale;
+            // float32, the reference's operation order (base.py:292-293): mean; 1/sqrt(mean*(1-0.5*mean))
+            mu = sum / n_keep;
+            d = 1.0f / sqrtf(mu * (1.0f - 0.5f * mu));
+            mu_out[e] = mu;
+            if (colsum_out) colsum_out[e] = (int32_t)sum;
+        }
+        s_mu[threadIdx.x] = mu;
+        s_d[threadIdx.x] = d;
     }
-    for (int c = 0; c < n_sketch + n_norm; ++c) {
-        float v = 0.f;
-        if (live) {
+    __syncthreads();
+    for (int tile = 0; tile * 16 < ones; ++tile) {
+        const int c = tile * 16 + c16;
+        const bool colok = c < ones;
+        float mx = 0.f;
+        double s2 = 0.0;
+        if (colok) {
             const double inv_s = 1.0 / (double)scale[c];
-            double pc;
-            if (i8) {
-                const int* Pi = reinterpret_cast<const int*>(P) + (int64_t)e * 3 * ncol_p + c;
-                pc = ((double)Pi[0] + (double)Pi[ncol_p] * (1.0 / 128.0) + (double)Pi[2 * ncol_p] * (1.0 / 16384.0)) * inv_s;
-            } else {
-                pc = (double)P[(int64_t)e * ncol_p + c] * (double)pscale * inv_s;
+            const double cs = csum[c] * inv_s;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lo = i * 16 + el, e = ebase + lo;
+                if (e < n_entries) {
+                    double pc;
+                    if (i8) {
+                        const int* Pi = reinterpret_cast<const int*>(P) + (int64_t)e * 3 * ncol_p + c;
+                        pc = ((double)Pi[0] + (double)Pi[ncol_p] * (1.0 / 128.0) + (double)Pi[2 * ncol_p] * (1.0 / 16384.0)) * inv_s;
+                    } else {
+                        pc = (double)P[(int64_t)e * ncol_p + c] * (double)pscale * inv_s;
+                    }
+                    const float d = s_d[lo];
+                    const float v = (float)((double)d * (pc - (double)s_mu[lo] * cs));
+                    if (c < n_sketch) {
+                        const float w = d * v;
+                        Wtmp[(int64_t)e * n_sketch + c] = w;
+                        mx = fmaxf(mx, fabsf(w));
+                    } else {
+                        s2 += (double)v * (double)v;
+                    }
+                }
             }
-            v = (float)((double)d * (pc - (double)mu * (csum[c] * inv_s)));
         }
-        if (c < n_sketch) {
-            float w = d * v;
-            if (live) Wtmp[(int64_t)e * n_sketch + c] = w;
-            float m = live ? fabsf(w) : 0.f;
-            for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-            if ((threadIdx.x & 63) == 0) atomicMax(&wmax_bits[c], __float_as_uint(m));
-        } else {
-            double s2 = live ? (double)v * (double)v : 0.0;
-            for (int off = 32; off; off >>= 1) s2 += __shfl_xor(s2, off);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&norm_acc[c - n_sketch], s2);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        s2 += __shfl_xor(s2, 16);
+        s2 += __shfl_xor(s2, 32);
+        if ((threadIdx.x & 63) < 16) {
+            s_max[wave][c16] = mx;
+            s_nrm[wave][c16] = s2;
         }
+        __syncthreads();
+        if (threadIdx.x < 16 && colok) {
+            if (c < n_sketch) {
+                const float m = fmaxf(fmaxf(s_max[0][c16], s_max[1][c16]), fmaxf(s_max[2][c16], s_max[3][c16]));
+                atomicMax(&wmax_bits[c], __float_as_uint(m));
+            } else {
+                atomicAdd(&norm_acc[c - n_sketch], s_nrm[0][c16] + s_nrm[1][c16] + s_nrm[2][c16] + s_nrm[3][c16]);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -646,11 +683,18 @@ __global__ void mid_dom1_kernel(const float* __restrict__ PG, const float* __res
 // mid 2: W -> fp16 operand image for GEMM 2 + rank-1 correction  corr[c] = sum_e mu_e * Wh[e][c]
 // Wfrag layout: [kb][part][tile][lane 64][8 halves]; lane = q*16 + c; element j <-> entry 32 kb + 8 q + j
 // ------------------------------------------------------------------------------------------------
+// Also (folded in to save two launches per entry list): the row list padded to a multiple of 32 for GEMM 2
+// (pad rows read rows[0]; their W is zero) and the hand-over of the norm sums of mid 1 to the caller's buffer.
 template <int PARTS>
 __global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restrict__ mu, int n_entries,
                             int n_kb, int n_sketch, int nto, const uint32_t* __restrict__ wmax_bits,
-                            half8* __restrict__ wfrag, double* __restrict__ corr, float* __restrict__ wscale) {
+                            half8* __restrict__ wfrag, double* __restrict__ corr, float* __restrict__ wscale,
+                            const int32_t* __restrict__ rows, int32_t* __restrict__ rows32,
+                            const double* __restrict__ norm_src, double* __restrict__ norm_dst, int n_norm,
+                            int norm_accumulate) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rows32 && gid < (int64_t)n_kb * 32) rows32[gid] = gid < n_entries ? rows[gid] : rows[0];
+    if (norm_dst && gid < n_norm) norm_dst[gid] = norm_accumulate ? norm_dst[gid] + norm_src[gid] : norm_src[gid];
     const int lane = gid & 63;
     int64_t rest = gid >> 6;
     const int tile = rest % nto;
@@ -1452,6 +1496,21 @@ __global__ void add_partials_kernel(float4* __restrict__ out, const float4* __re
     }
 }
 
+// out[i] = sum_j (double) blocks[j * stride + i]: the float64 "aggregate" over per-block float32 sketches
+// (base_streaming.py:21-32 / base.py:468-471) in one streaming pass, blocks added in order j = 0, 1, ...
+__global__ void sum_blocks_kernel(const float* __restrict__ blocks, int n_blocks, int64_t stride, int64_t n4,
+                                  double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int j = 0; j < n_blocks; ++j) {
+            const float4 v = reinterpret_cast<const float4*>(blocks + (int64_t)j * stride)[i];
+            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+        }
+        double* o = out + 4 * i;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+    }
+}
+
 __global__ void add_norm_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, int accumulate) {
     const int i = threadIdx.x;
     if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
@@ -1569,7 +1628,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
 
     // ---- W (float) -> operand image + rank-1 correction, then GEMM 2 with genotype view gv into outp
     auto run_gemm2 = [&](int gv, const float* Wsrc, const float* coef, const uint32_t* wmaxp, int n, int n_kb, float* outp,
-                         bool acc_now, int set) -> int {
+                         bool acc_now, int set, const int32_t* rows, const double* nsrc, double* ndst) -> int {
         {
             ProfScope ps(e, stream, 1);
             const int64_t threads = (int64_t)n_kb * e->parts * e->nto * 64;
@@ -1577,8 +1636,10 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             if (g2i8) {
                 const int64_t th = (int64_t)n_kb * 3 * 64;
                 mid2_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, wmaxp, (int4v*)e->wfrag, e->corr, e->wscale);
-            } else if (e->parts == 2) mid2_kernel<2><<<grid, 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale);
-            else mid2_kernel<1><<<grid, 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale);
+                pad_rows_kernel<<<(n_kb * 64 + 255) / 256, 256, 0, stream>>>(rows, n, n_kb * 64, e->rows32);
+                if (ndst) add_norm_kernel<<<1, 64, 0, stream>>>(nsrc, ndst, e->n_norm, acc_now);
+            } else if (e->parts == 2) mid2_kernel<2><<<grid, 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale, rows, e->rows32, nsrc, ndst, e->n_norm, acc_now);
+            else mid2_kernel<1><<<grid, 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale, rows, e->rows32, nsrc, ndst, e->n_norm, acc_now);
         }
         if (piped) {      // GEMM 2 goes to stream B, behind this sub-block's mid kernels on stream A
             HIPCHK(hipEventRecord(e->evA[set], e->sA));
@@ -1666,21 +1727,21 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             e->sub_counter++;
             const bool acc_now = accumulate || !first;
             HIPCHK(hipMemsetAsync(e->ws, 0, e->zero_bytes, stream));
-            pad_rows_kernel<<<(n32 + 255) / 256, 256, 0, stream>>>(rows, n, n32, e->rows32);
             run_gemm1(0, rows, n, e->P);
             {
                 ProfScope ps(e, stream, 1);
-                mid1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
+                mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
                                                                  (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->normacc,
                                                                  out_colsum ? out_colsum + offsets_host[b] + s0 : nullptr);
-                if (e->n_norm) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc, normb, e->n_norm, acc_now);
+                if (e->n_norm && !e->n_sketch) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc, normb, e->n_norm, acc_now);
             }
             if (!e->n_sketch && piped) {
                 HIPCHK(hipEventRecord(e->evA[set], e->sA));
                 HIPCHK(hipStreamWaitEvent(sB2, e->evA[set], 0));
             }
             if (e->n_sketch) {
-                const int rc = run_gemm2(0, e->Wtmp, e->mu, e->wmax, n, n_kb, outb, acc_now, set);
+                const int rc = run_gemm2(0, e->Wtmp, e->mu, e->wmax, n, n_kb, outb, acc_now, set, rows, e->n_norm ? e->normacc : nullptr,
+                                         e->n_norm ? normb : nullptr);
                 if (rc) return rc;
             }
             if (dom) {
@@ -1694,13 +1755,14 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                     mid_dom1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->P2, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale,
                                                                          e->csum, (float)e->n_keep, e->cmu, e->Wtmp, e->Wtmp2, e->wmax, e->wmax2,
                                                                          e->normacc2);
-                    if (e->n_norm) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc2, normd, e->n_norm, acc_now);
+                    if (e->n_norm && !e->n_sketch) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc2, normd, e->n_norm, acc_now);
                 }
                 if (e->n_sketch) {
-                    int rc = run_gemm2(0, e->Wtmp, e->cmu, e->wmax, n, n_kb, outd, acc_now, set);
+                    int rc = run_gemm2(0, e->Wtmp, e->cmu, e->wmax, n, n_kb, outd, acc_now, set, rows, e->n_norm ? e->normacc2 : nullptr,
+                                       e->n_norm ? normd : nullptr);
                     if (rc) return rc;
                     HIPCHK(hipMemsetAsync(e->corr, 0, 16 * kMaxTiles * sizeof(double), stream));
-                    rc = run_gemm2(1, e->Wtmp2, e->zcoef, e->wmax2, n, n_kb, outd, true, set);
+                    rc = run_gemm2(1, e->Wtmp2, e->zcoef, e->wmax2, n, n_kb, outd, true, set, rows, nullptr, nullptr);
                     if (rc) return rc;
                 }
             }
@@ -1771,6 +1833,16 @@ extern "C" int pyrhe_engine_block_stats(pyrhe_engine_t* e, const uint8_t* packed
     if (n_rows <= 0) return PYRHE_OK;
     HIPCHK(hipSetDevice(e->device));
     block_stats_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(packed, e->pitch, n_rows, e->keepmask, out_sum, out_nmiss);
+    HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
+extern "C" int pyrhe_sum_blocks(const float* blocks, int n_blocks, int64_t block_stride, int64_t n, double* out,
+                                void* stream_) {
+    if (!blocks || !out) return fail(PYRHE_EINVAL, "NULL argument");
+    if (n <= 0 || n % 4 || block_stride % 4) return fail(PYRHE_EINVAL, "n and block_stride must be positive multiples of 4");
+    if (n_blocks < 0) return fail(PYRHE_EINVAL, "n_blocks negative");
+    sum_blocks_kernel<<<4096, 256, 0, (hipStream_t)stream_>>>(blocks, n_blocks, block_stride, n / 4, out);
     HIPCHK(hipGetLastError());
     return PYRHE_OK;
 }

@@ -41,6 +41,7 @@ SYMBOLS = {
     "pyrhe_engine_join": (_i32, [_vp, _vp]),
     "pyrhe_engine_set_pipeline": (_i32, [_vp, _i32]),
     "pyrhe_decode_rows": (_i32, [_vp, _i64, _i64, _vp, _vp]),
+    "pyrhe_sum_blocks": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
     "pyrhe_synth_genotypes": (_i32, [_vp, _i64, _i64, _i64, _u64, _i64, _vp]),
     "pyrhe_engine_info": (_i64, [_vp, _i32]),
     "pyrhe_engine_profile": (_i32, [_vp, _i32]),
@@ -133,6 +134,20 @@ def synth_genotypes(n_rows: int, n_samples: int, seed: int, row0: int, device, o
             n = min(step, n_rows - r)
             _check(lib.pyrhe_synth_genotypes(C.c_void_p(out[r].data_ptr()), n, pitch, n_samples, seed & (2**64 - 1), row0 + r,
                                              _stream_ptr(device)), "pyrhe_synth_genotypes")
+    return out
+
+
+def sum_blocks(blocks: torch.Tensor) -> torch.Tensor:
+    """``blocks [jl, ...]`` float32 (contiguous) -> float64 sum over the first dimension, by the HIP kernel when the tensor
+    lives on a GPU (``pyrhe_sum_blocks``), by torch on the CPU (multi-process CPU tests of the driver only)."""
+    if blocks.device.type != "cuda" or blocks.shape[0] == 0 or (blocks[0].numel() % 4):
+        return blocks.sum(dim=0, dtype=torch.float64) if blocks.shape[0] else torch.zeros(blocks.shape[1:], dtype=torch.float64, device=blocks.device)
+    assert blocks.dtype == torch.float32 and blocks.is_contiguous()
+    out = torch.empty(blocks.shape[1:], dtype=torch.float64, device=blocks.device)
+    n = blocks[0].numel()
+    with torch.cuda.device(blocks.device):
+        _check(load_library().pyrhe_sum_blocks(_ptr(blocks), blocks.shape[0], n, n, _ptr(out), _stream_ptr(blocks.device)),
+               "pyrhe_sum_blocks")
     return out
 
 

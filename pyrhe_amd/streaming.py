@@ -24,6 +24,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .engine import sum_blocks
+
 
 # ----------------------------------------------------------------------------- block plan
 def block_range(j: int, n_snp: int, n_jack: int) -> Tuple[int, int]:
@@ -399,11 +401,11 @@ class SketchRunner:
             # Block sums as ONE float64 reduction over the stored per-block sketches (the reference adds the blocks one
             # by one in float64, base.py:468-471; any order agrees to 1e-16).  U is linear, so the "fixed" UXXz total is
             # U applied to the total (float32 rounding order differs from per-block application at the 1e-7 level).
-            tot_sk = [b.sum(dim=0, dtype=f64) if jl else torch.zeros(b.shape[1:], dtype=f64, device=dev) for b in self.blocks_sk]
+            tot_sk = [sum_blocks(b) for b in self.blocks_sk]
             tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
             tot_skd = tot_nmd = None
             if self.dom:
-                tot_skd = [b.sum(dim=0, dtype=f64) if jl else torch.zeros(b.shape[1:], dtype=f64, device=dev) for b in self.blocks_skd]
+                tot_skd = [sum_blocks(b) for b in self.blocks_skd]
                 tot_nmd = [b[:jl].sum(dim=0) for b in self.blocks_nmd]
             tot_A, tot_C, tot_r = self._block_estimates(tot_sk, tot_nm, tot_skd, tot_nmd)
             tot_A, tot_r = tot_A.contiguous(), tot_r.clone()
