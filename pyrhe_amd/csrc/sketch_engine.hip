@@ -527,13 +527,42 @@ __global__ __launch_bounds__(256) void gemm1_i8_kernel(const uint8_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Segment table of one chunk of entries, passed to the kernels BY VALUE (kernel argument: no upload, no sync).
+// A chunk is a run of the caller's concatenated per-bin entry lists; segment g = the part of bin `bin[g]` inside the
+// chunk = chunk entries start[g] .. start[g+1]-1.  GEMM 1 does not care about bins (X^T R is per SNP) and runs once
+// over the whole chunk; everything that is per bin -- the column maxima / scales of W, the rank-1 corrections, the
+// norm sums, GEMM 2's K range and its output slab -- is indexed by segment (stride kSegCols columns).  GEMM 2 walks
+// K blocks of 32 entries, so each segment owns K blocks kb0[g] .. kb0[g+1]-1 (its tail padded with zero-weight rows).
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxSeg = 64;
+constexpr int kSegCols = 32;
+struct SegTab {
+    int nseg;
+    int start[kMaxSeg + 1];
+    int kb0[kMaxSeg + 1];
+    int bin[kMaxSeg];
+    unsigned char acc[kMaxSeg];   // 1: add to the caller's outputs of that bin, 0: overwrite
+};
+__device__ __forceinline__ int seg_of_entry(const SegTab& t, int e) {
+    int g = 0;
+    while (g + 1 < t.nseg && e >= t.start[g + 1]) ++g;
+    return g;
+}
+__device__ __forceinline__ int seg_of_kb(const SegTab& t, int kb) {
+    int g = 0;
+    while (g + 1 < t.nseg && kb >= t.kb0[g + 1]) ++g;
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
 // mid 1: per entry statistics, V = X^T R, norm accumulation, W = D V (float32) + column maxima
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mid1_kernel(const float* __restrict__ P, float pscale, int i8, int n_entries, int ncol_p,
                                                    int n_sketch, int n_norm, const float* __restrict__ scale,
                                                    const double* __restrict__ csum, float n_keep, float* __restrict__ mu_out,
                                                    float* __restrict__ Wtmp, uint32_t* __restrict__ wmax_bits,
-                                                   double* __restrict__ norm_acc, int32_t* __restrict__ colsum_out) {
+                                                   double* __restrict__ norm_acc, int32_t* __restrict__ colsum_out,
+                                                   const SegTab tab) {
     // workgroup = 64 entries; thread (c16, el): column c16 of a 16-column tile, entries el, el+16, el+32, el+48.
     // Consecutive lanes read consecutive columns of one entry (coalesced); column maxima / norm sums are kept in
     // registers over the 4 entries, folded over the wave by 2 shuffles and over the 4 waves through LDS.
@@ -543,6 +572,12 @@ __global__ __launch_bounds__(256) void mid1_kernel(const float* __restrict__ P, 
     const int c16 = threadIdx.x & 15, el = threadIdx.x >> 4, wave = threadIdx.x >> 6;
     const int ones = n_sketch + n_norm;
     const int ebase = blockIdx.x * 64;
+    // segment of this workgroup's entries; a workgroup that straddles a boundary (at most nseg-1 of them) skips the
+    // in-register reduction and sends every entry's contribution straight to its segment's slot
+    const int g0 = seg_of_entry(tab, ebase);
+    const bool mixed = seg_of_entry(tab, min(ebase + 63, n_entries - 1)) != g0;
+    wmax_bits += g0 * kSegCols;
+    norm_acc += g0 * kSegCols;
     if (threadIdx.x < 64) {
         const int e = ebase + threadIdx.x;
         float mu = 0.f, d = 0.f;
@@ -584,9 +619,11 @@ __global__ __launch_bounds__(256) void mid1_kernel(const float* __restrict__ P, 
                     if (c < n_sketch) {
                         const float w = d * v;
                         Wtmp[(int64_t)e * n_sketch + c] = w;
-                        mx = fmaxf(mx, fabsf(w));
+                        if (mixed) atomicMax(&wmax_bits[(seg_of_entry(tab, e) - g0) * kSegCols + c], __float_as_uint(fabsf(w)));
+                        else mx = fmaxf(mx, fabsf(w));
                     } else {
-                        s2 += (double)v * (double)v;
+                        if (mixed) atomicAdd(&norm_acc[(seg_of_entry(tab, e) - g0) * kSegCols + c - n_sketch], (double)v * (double)v);
+                        else s2 += (double)v * (double)v;
                     }
                 }
             }
@@ -685,16 +722,28 @@ __global__ void mid_dom1_kernel(const float* __restrict__ PG, const float* __res
 // ------------------------------------------------------------------------------------------------
 // Also (folded in to save two launches per entry list): the row list padded to a multiple of 32 for GEMM 2
 // (pad rows read rows[0]; their W is zero) and the hand-over of the norm sums of mid 1 to the caller's buffer.
+// Per segment (see SegTab): scales, corrections and norm sums live at [g * kSegCols + c]; norm_dst is the caller's
+// [nbin][n_norm] array, segment g lands in row tab.bin[g].
 template <int PARTS>
-__global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restrict__ mu, int n_entries,
-                            int n_kb, int n_sketch, int nto, const uint32_t* __restrict__ wmax_bits,
+__global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restrict__ mu,
+                            int n_sketch, int nto, const uint32_t* __restrict__ wmax_bits,
                             half8* __restrict__ wfrag, double* __restrict__ corr, float* __restrict__ wscale,
                             const int32_t* __restrict__ rows, int32_t* __restrict__ rows32,
                             const double* __restrict__ norm_src, double* __restrict__ norm_dst, int n_norm,
-                            int norm_accumulate) {
+                            const SegTab tab) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (rows32 && gid < (int64_t)n_kb * 32) rows32[gid] = gid < n_entries ? rows[gid] : rows[0];
-    if (norm_dst && gid < n_norm) norm_dst[gid] = norm_accumulate ? norm_dst[gid] + norm_src[gid] : norm_src[gid];
+    const int n_kb = tab.kb0[tab.nseg];
+    if (rows32 && gid < (int64_t)n_kb * 32) {
+        const int g = seg_of_kb(tab, (int)(gid >> 5));
+        const int idx = (int)gid - tab.kb0[g] * 32;
+        rows32[gid] = rows[tab.start[g] + (idx < tab.start[g + 1] - tab.start[g] ? idx : 0)];
+    }
+    if (norm_dst && gid < (int64_t)tab.nseg * n_norm) {
+        const int g = (int)gid / n_norm, i = (int)gid % n_norm;
+        double* d = norm_dst + (int64_t)tab.bin[g] * n_norm + i;
+        const double v = norm_src[g * kSegCols + i];
+        *d = tab.acc[g] ? *d + v : v;
+    }
     const int lane = gid & 63;
     int64_t rest = gid >> 6;
     const int tile = rest % nto;
@@ -702,6 +751,11 @@ __global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restr
     const int part = rest % PARTS;
     const int64_t kb = rest / PARTS;
     if (kb >= n_kb) return;
+    const int g = seg_of_kb(tab, (int)kb);
+    const int kbl = (int)kb - tab.kb0[g], ebase = tab.start[g], n_entries = tab.start[g + 1];
+    wmax_bits += g * kSegCols;
+    corr += g * kSegCols;
+    wscale += g * kSegCols;
     const int c = tile * 16 + (lane & 15);
     const int q = lane >> 4;
     const float s = c < n_sketch ? pow2_scale(__uint_as_float(wmax_bits[c])) : 1.0f;
@@ -712,7 +766,7 @@ __global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restr
         _Float16 v2[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int e = kb * 32 + q * 8 + jj * 2 + b;
+            const int e = ebase + kbl * 32 + q * 8 + jj * 2 + b;
             float x = 0.f, m = 0.f;
             if (e < n_entries && c < n_sketch) {
                 x = Wtmp[(int64_t)e * n_sketch + c] * s;
@@ -731,7 +785,7 @@ __global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restr
     acc += __shfl_xor(acc, 16);
     acc += __shfl_xor(acc, 32);
     if (q == 0 && c < n_sketch) atomicAdd(&corr[c], acc);
-    if (kb == 0 && part == 0 && q == 0) wscale[c] = s;
+    if (kbl == 0 && part == 0 && q == 0) wscale[c] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -753,9 +807,11 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const uint8_t* __restrict
                                                     const float* __restrict__ wscale,
                                                     const float* __restrict__ keep, int n_sketch,
                                                     int64_t n_pad, float* __restrict__ out, int mode,
-                                                    float* __restrict__ partial) {
+                                                    float* __restrict__ partial, const SegTab tab) {
     // mode: 0 store, 1 read-modify-write, 2 atomicAdd.  With `partial` != NULL, K split y > 0 stores its share
     // into partial[y-1] (summed into `out` by add_partials_kernel) instead of touching `out`.
+    // Segment mode (tab.nseg > 0): blockIdx.y is a SEGMENT instead of a K split -- all bins of a chunk in one launch;
+    // the workgroup takes its K range, scales, correction, output slab and store mode from the table.
     constexpr int NU = 16 * IW;                  // MFMAs (= samples per lane) per step
     constexpr int NS = 3;                        // register ring depth
     extern __shared__ __attribute__((aligned(16))) int32_t s_rows[];
@@ -763,8 +819,20 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const uint8_t* __restrict
     const int wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     const int64_t grp = (int64_t)blockIdx.x * 4 + wave;
-    const int kb0 = blockIdx.y * kb_per_split;
-    const int kb1 = min(kb0 + kb_per_split, n_kb);
+    const bool segmode = tab.nseg > 0;
+    int kb0 = blockIdx.y * kb_per_split;
+    int kb1 = min(kb0 + kb_per_split, n_kb);
+    int ysplit = blockIdx.y;
+    if (segmode) {
+        const int g = blockIdx.y;
+        kb0 = tab.kb0[g];
+        kb1 = tab.kb0[g + 1];
+        corr += g * kSegCols;
+        wscale += g * kSegCols;
+        out += (int64_t)tab.bin[g] * n_sketch * n_pad;
+        mode = tab.acc[g] ? 1 : 0;
+        ysplit = 0;
+    }
     if (kb0 >= kb1) return;
     for (int i = threadIdx.x; i < (kb1 - kb0) * 32; i += 256) s_rows[i] = rows32[(int64_t)kb0 * 32 + i];
     __syncthreads();
@@ -884,11 +952,11 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const uint8_t* __restrict
         for (int reg = 0; reg < 4; ++reg) {
             const int c = t * 16 + 4 * q + reg;
             if (c >= n_sketch) continue;
-            const float cr = blockIdx.y == 0 ? (float)corr[c] : 0.f;
+            const float cr = ysplit == 0 ? (float)corr[c] : 0.f;
             const float inv = 1.0f / wscale[c];
             float* dst = out + (int64_t)c * n_pad + i0;
-            if (partial && blockIdx.y > 0) {
-                dst = partial + ((int64_t)(blockIdx.y - 1) * n_sketch + c) * n_pad + i0;
+            if (partial && ysplit > 0) {
+                dst = partial + ((int64_t)(ysplit - 1) * n_sketch + c) * n_pad + i0;
                 mode = 0;
             }
 #pragma unroll
@@ -1312,15 +1380,17 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t oP = carve(S * ncolmax * sizeof(float) * (precision == PYRHE_PREC_I8X3 ? 3 : 1));
-    const size_t oWmax = carve(ncolmax * sizeof(uint32_t));
-    const size_t oCorr = carve(ncolmax * sizeof(double));
-    const size_t oNorm = carve(ncolmax * sizeof(double));
+    static_assert(kSegCols == 16 * kMaxTiles, "segment slots hold one value per logical column");
+    const size_t oWmax = carve((size_t)kMaxSeg * kSegCols * sizeof(uint32_t));
+    const size_t oCorr = carve((size_t)kMaxSeg * kSegCols * sizeof(double));
+    const size_t oNorm = carve((size_t)kMaxSeg * kSegCols * sizeof(double));
     e->zero_bytes = off;
     const size_t oMu = carve(S * sizeof(float));
     const size_t oWtmp = carve(S * ncolmax * sizeof(float));
-    const size_t oWscale = carve(ncolmax * sizeof(float));
-    const size_t oWfrag = carve((S / 32) * e->parts * kMaxTiles * 64 * sizeof(half8));
-    const size_t oRows = carve((S + 64) * sizeof(int32_t));
+    const size_t oWscale = carve((size_t)kMaxSeg * kSegCols * sizeof(float));
+    // every segment pads its tail to a 32-entry K block (64 for the int8 GEMM 2)
+    const size_t oWfrag = carve((S / 32 + kMaxSeg) * e->parts * kMaxTiles * 64 * sizeof(half8));
+    const size_t oRows = carve((S + 64 + 32 * kMaxSeg) * sizeof(int32_t));
     e->ws_bytes = off;
     for (int i = 0; i < 2; ++i) {
         uint8_t* base = nullptr;
@@ -1475,12 +1545,13 @@ static void launch_gemm1(pyrhe_engine* e, const uint8_t* packed, const int32_t* 
 
 template <int NTO, int PARTS, int IW, bool EXACT, int GV = 0>
 static void launch_gemm2(pyrhe_engine* e, const uint8_t* packed, int n_kb, int kbps, int splits, const float* fill,
-                         float* out, int mode, float* partial, hipStream_t stream) {
+                         float* out, int mode, float* partial, hipStream_t stream, const SegTab& tab) {
+    // segment mode (tab.nseg > 0): `splits` = number of segments, `kbps` = K blocks of the longest one (LDS row list)
     dim3 grid((unsigned)((e->n_pad + 1024 * IW - 1) / (1024 * IW)), splits);
     if (fill)
-        gemm2_kernel<NTO, PARTS, IW, EXACT, true, GV><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial);
+        gemm2_kernel<NTO, PARTS, IW, EXACT, true, GV><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial, tab);
     else
-        gemm2_kernel<NTO, PARTS, IW, EXACT, false, GV><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial);
+        gemm2_kernel<NTO, PARTS, IW, EXACT, false, GV><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial, tab);
 }
 
 // out[i] += sum_s partial[s][i]   (K-split partial sketches; float4 granularity)
@@ -1627,8 +1698,13 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     };
 
     // ---- W (float) -> operand image + rank-1 correction, then GEMM 2 with genotype view gv into outp
+    // `tab` describes the chunk's segments for the mid kernel; segmode = GEMM 2 too runs all segments in one launch
+    // (outp / ndst are then the caller's [nbin] arrays, indexed by tab.bin), otherwise tab has the one segment of the
+    // list and GEMM 2 may split K over blockIdx.y.
+    static const SegTab no_tab = {};
     auto run_gemm2 = [&](int gv, const float* Wsrc, const float* coef, const uint32_t* wmaxp, int n, int n_kb, float* outp,
-                         bool acc_now, int set, const int32_t* rows, const double* nsrc, double* ndst) -> int {
+                         bool acc_now, int set, const int32_t* rows, const double* nsrc, double* ndst, const SegTab& tab,
+                         bool segmode) -> int {
         {
             ProfScope ps(e, stream, 1);
             const int64_t threads = (int64_t)n_kb * e->parts * e->nto * 64;
@@ -1638,8 +1714,8 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 mid2_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, wmaxp, (int4v*)e->wfrag, e->corr, e->wscale);
                 pad_rows_kernel<<<(n_kb * 64 + 255) / 256, 256, 0, stream>>>(rows, n, n_kb * 64, e->rows32);
                 if (ndst) add_norm_kernel<<<1, 64, 0, stream>>>(nsrc, ndst, e->n_norm, acc_now);
-            } else if (e->parts == 2) mid2_kernel<2><<<grid, 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale, rows, e->rows32, nsrc, ndst, e->n_norm, acc_now);
-            else mid2_kernel<1><<<grid, 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale, rows, e->rows32, nsrc, ndst, e->n_norm, acc_now);
+            } else if (e->parts == 2) mid2_kernel<2><<<grid, 256, 0, stream>>>(Wsrc, coef, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale, rows, e->rows32, nsrc, ndst, e->n_norm, tab);
+            else mid2_kernel<1><<<grid, 256, 0, stream>>>(Wsrc, coef, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale, rows, e->rows32, nsrc, ndst, e->n_norm, tab);
         }
         if (piped) {      // GEMM 2 goes to stream B, behind this sub-block's mid kernels on stream A
             HIPCHK(hipEventRecord(e->evA[set], e->sA));
@@ -1656,11 +1732,19 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         if (const char* ev = getenv("PYRHE_G2_SPLITS")) splits = atoi(ev);
         splits = std::max(splits, (n_kb + (g2i8 ? 255 : 511)) / (g2i8 ? 256 : 512));   // row list of a K range lives in LDS: <= 64 KiB
         splits = std::max(1, std::min(splits, n_kb));
-        const int kbps = (n_kb + splits - 1) / splits;
+        int kbps = (n_kb + splits - 1) / splits;
         splits = (n_kb + kbps - 1) / kbps;
+        if (segmode) {
+            splits = tab.nseg;
+            kbps = 0;
+            for (int g = 0; g < tab.nseg; ++g) kbps = std::max(kbps, tab.kb0[g + 1] - tab.kb0[g]);
+        }
+        const SegTab& gtab = segmode ? tab : no_tab;
         int mode;
         float* partial = nullptr;
-        if (splits > 1 && splits <= 16) {
+        if (segmode) {
+            mode = 0;
+        } else if (splits > 1 && splits <= 16) {
             // K splits write private partials, summed by one streaming kernel (no atomics)
             const size_t need = (size_t)(splits - 1) * sk_stride * sizeof(float);
             if (e->partial_bytes < need) {
@@ -1677,7 +1761,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             mode = acc_now ? 1 : 0;
         }
         ProfScope ps(e, sB2, 2);
-#define G2(NTO_, PARTS_, IW_, EX_, GV_) launch_gemm2<NTO_, PARTS_, IW_, EX_, GV_>(e, packed, n_kb, kbps, splits, fill, outp, mode, partial, sB2)
+#define G2(NTO_, PARTS_, IW_, EX_, GV_) launch_gemm2<NTO_, PARTS_, IW_, EX_, GV_>(e, packed, n_kb, kbps, splits, fill, outp, mode, partial, sB2, gtab)
         if (g2i8) {
             dim3 grid((unsigned)((e->n_pad + 1023) / 1024), splits);
             const size_t lds = (size_t)kbps * 256;
@@ -1700,7 +1784,66 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         return PYRHE_OK;
     };
 
-    for (int b = 0; b < nbin; ++b) {
+    // ---- several bins, additive sketch only: GEMM 1 once per chunk of the concatenated lists, per-bin work by segment
+    const bool segflow = nbin > 1 && !dom && !g2i8;
+    if (segflow) {
+        std::vector<char> touched(nbin, 0);
+        for (int b = 0; b < nbin; ++b)
+            if (offsets_host[b + 1] == offsets_host[b] && !accumulate) {
+                if (out_sketch) HIPCHK(hipMemsetAsync(out_sketch + b * sk_stride, 0, sk_stride * sizeof(float), sB2));
+                if (out_norm && e->n_norm) HIPCHK(hipMemsetAsync(out_norm + (int64_t)b * e->n_norm, 0, e->n_norm * sizeof(double), stream));
+            }
+        const int64_t total = offsets_host[nbin];
+        const int64_t seg_cap = std::min<int64_t>(e->sub_snps, 512 * 32);   // GEMM 2 keeps a segment's row list in LDS
+        int b = 0;
+        for (int64_t pos = 0; pos < total;) {
+            SegTab tab = {};
+            const int64_t chunk0 = pos;
+            int n = 0, kb = 0;
+            while (pos < total && n < e->sub_snps && tab.nseg < kMaxSeg) {
+                while (offsets_host[b + 1] <= pos) ++b;
+                const int take = (int)std::min<int64_t>(std::min<int64_t>(offsets_host[b + 1] - pos, e->sub_snps - n), seg_cap);
+                const int g = tab.nseg++;
+                tab.start[g] = n;
+                tab.kb0[g] = kb;
+                tab.bin[g] = b;
+                tab.acc[g] = (accumulate || touched[b]) ? 1 : 0;
+                touched[b] = 1;
+                n += take;
+                kb += (take + 31) / 32;
+                pos += take;
+            }
+            tab.start[tab.nseg] = n;
+            tab.kb0[tab.nseg] = kb;
+            const int32_t* rows = entries + chunk0;
+            const int set = (int)(e->sub_counter & 1);
+            e->use_set(set);
+            if (piped && e->sub_counter >= 2) HIPCHK(hipStreamWaitEvent(e->sA, e->evB[set], 0));
+            e->sub_counter++;
+            HIPCHK(hipMemsetAsync(e->ws, 0, e->zero_bytes, stream));
+            run_gemm1(0, rows, n, e->P);
+            {
+                ProfScope ps(e, stream, 1);
+                mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
+                                                                 (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->normacc,
+                                                                 out_colsum ? out_colsum + chunk0 : nullptr, tab);
+            }
+            if (e->n_sketch) {
+                const int rc = run_gemm2(0, e->Wtmp, e->mu, e->wmax, n, kb, out_sketch, false, set, rows, e->n_norm ? e->normacc : nullptr,
+                                         e->n_norm ? out_norm : nullptr, tab, true);
+                if (rc) return rc;
+            } else {
+                for (int g = 0; g < tab.nseg && e->n_norm; ++g)
+                    add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc + g * kSegCols, out_norm + (int64_t)tab.bin[g] * e->n_norm, e->n_norm, tab.acc[g]);
+                if (piped) {
+                    HIPCHK(hipEventRecord(e->evA[set], e->sA));
+                    HIPCHK(hipStreamWaitEvent(sB2, e->evA[set], 0));
+                }
+            }
+            if (piped) HIPCHK(hipEventRecord(e->evB[set], sB2));
+        }
+    }
+    for (int b = 0; b < nbin && !segflow; ++b) {
         const int64_t n_b = offsets_host[b + 1] - offsets_host[b];
         float* outb = out_sketch ? out_sketch + b * sk_stride : nullptr;
         double* normb = out_norm ? out_norm + (int64_t)b * e->n_norm : nullptr;
@@ -1726,13 +1869,18 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             if (piped && e->sub_counter >= 2) HIPCHK(hipStreamWaitEvent(e->sA, e->evB[set], 0));   // GEMM 2 of sub-block g-2 is done with this set
             e->sub_counter++;
             const bool acc_now = accumulate || !first;
+            SegTab tab = {};
+            tab.nseg = 1;
+            tab.start[1] = n;
+            tab.kb0[1] = n_kb;
+            tab.acc[0] = acc_now ? 1 : 0;
             HIPCHK(hipMemsetAsync(e->ws, 0, e->zero_bytes, stream));
             run_gemm1(0, rows, n, e->P);
             {
                 ProfScope ps(e, stream, 1);
                 mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
                                                                  (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->normacc,
-                                                                 out_colsum ? out_colsum + offsets_host[b] + s0 : nullptr);
+                                                                 out_colsum ? out_colsum + offsets_host[b] + s0 : nullptr, tab);
                 if (e->n_norm && !e->n_sketch) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc, normb, e->n_norm, acc_now);
             }
             if (!e->n_sketch && piped) {
@@ -1741,7 +1889,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             }
             if (e->n_sketch) {
                 const int rc = run_gemm2(0, e->Wtmp, e->mu, e->wmax, n, n_kb, outb, acc_now, set, rows, e->n_norm ? e->normacc : nullptr,
-                                         e->n_norm ? normb : nullptr);
+                                         e->n_norm ? normb : nullptr, tab, false);
                 if (rc) return rc;
             }
             if (dom) {
@@ -1759,10 +1907,11 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 }
                 if (e->n_sketch) {
                     int rc = run_gemm2(0, e->Wtmp, e->cmu, e->wmax, n, n_kb, outd, acc_now, set, rows, e->n_norm ? e->normacc2 : nullptr,
-                                       e->n_norm ? normd : nullptr);
+                                       e->n_norm ? normd : nullptr, tab, false);
                     if (rc) return rc;
                     HIPCHK(hipMemsetAsync(e->corr, 0, 16 * kMaxTiles * sizeof(double), stream));
-                    rc = run_gemm2(1, e->Wtmp2, e->zcoef, e->wmax2, n, n_kb, outd, true, set, rows, nullptr, nullptr);
+                    tab.acc[0] = 1;
+                    rc = run_gemm2(1, e->Wtmp2, e->zcoef, e->wmax2, n, n_kb, outd, true, set, rows, nullptr, nullptr, tab, false);
                     if (rc) return rc;
                 }
             }

@@ -145,3 +145,50 @@ def test_block_stats_exact(dev):
     assert np.array_equal(s.cpu().numpy(), np.where(g < 0, 0, g).sum(axis=1))
     assert np.array_equal(nm.cpu().numpy(), (g < 0).sum(axis=1))
     eng.close()
+
+
+@pytest.mark.parametrize("precision", ["i8x3", "f16x2", "f16"])
+@pytest.mark.parametrize("with_fill", [False, True])
+def test_multibin_call_equals_one_call_per_bin(dev, precision, with_fill):
+    """Several bins in one call take the segmented flow (one GEMM 1 over the concatenated lists, per-bin scales,
+    corrections, norms and GEMM 2 ranges by segment); one call per bin takes the single-list flow.  Same results,
+    including: overlapping bins, an empty bin, bins shorter than a K block, lists cut by sub_snps chunks, accumulate."""
+    from pyrhe_amd import engine
+    n, m, k = 5000, 900, 10
+    rng = np.random.default_rng(5)
+    packed = engine.synth_genotypes(m, n, 77, 0, dev)
+    fill = None
+    if with_fill:
+        # plant missing calls (code 01) in the first byte of some rows and give those SNPs a fill value
+        rows = torch.as_tensor(rng.choice(m, 200, replace=False), device=dev)
+        packed[rows, 3] = (packed[rows, 3] & 0xF0) | 0x05
+        fill = torch.zeros(m, dtype=torch.float32, device=dev)
+        fill[rows] = torch.as_tensor(rng.integers(0, 3, 200), dtype=torch.float32, device=dev)
+    lists = [np.sort(rng.choice(m, sz, replace=False)).astype(np.int32) for sz in (311, 0, 17, 450, 64, 129)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+    entries = torch.from_numpy(np.concatenate(lists)).to(dev)
+    eng = engine.SketchEngine(n, n, max_entries=m, precision=precision, device=dev, sub_snps=256)
+    keep = eng.keep_vector([])
+    Z = torch.zeros((k, eng.n_pad), device=dev)
+    Z[:, :n] = torch.from_numpy(rng.standard_normal((k, n)).astype(np.float32)).to(dev)
+    y = torch.zeros((2, eng.n_pad), device=dev)
+    y[:, :n] = torch.from_numpy(rng.standard_normal((2, n)).astype(np.float32)).to(dev)
+    eng.set_rhs(Z, y, keep)
+    sk, nm, cs = eng.sketch_block(packed, entries, offs, fill=fill, want_colsum=True)
+    sk2, nm2, _ = eng.sketch_block(packed, entries, offs, fill=fill, out_sketch=sk.clone(), out_norm=nm.clone(), accumulate=True)
+    torch.cuda.synchronize()
+    tol = {"i8x3": 2e-6, "f16x2": 2e-6, "f16": 2e-3}[precision]
+    for b, lst in enumerate(lists):
+        if len(lst) == 0:
+            assert not sk[b].any() and not nm[b].any()
+            continue
+        e1 = torch.from_numpy(lst).to(dev)
+        s1, n1, c1 = eng.sketch_block(packed, e1, [0, len(lst)], fill=fill, want_colsum=True)
+        torch.cuda.synchronize()
+        assert torch.equal(cs[offs[b]:offs[b + 1]], c1)
+        scale = s1.abs().max().item()
+        assert (sk[b] - s1[0]).abs().max().item() <= tol * scale, b
+        assert torch.allclose(nm[b], n1[0], rtol=tol, atol=0), b
+        assert (sk2[b] - 2 * s1[0]).abs().max().item() <= 2 * tol * scale, b
+        assert torch.allclose(nm2[b], 2 * n1[0], rtol=tol, atol=0), b
+    eng.close()
