@@ -192,8 +192,16 @@ def main():
            "roofline": roofline}
 
     if args.verify:
+        barrier()
+        t0 = time.perf_counter()
         sysm = runner.pass2()
+        barrier()
+        t_pass2 = time.perf_counter() - t0
         sig = [est.solve_normal_equations(sysm.T[j], sysm.q[j].reshape(-1, 1)) for j in range(jn + 1)]
+        t_solve = time.perf_counter() - t0 - t_pass2
+        # end to end = one sketch pass (incl. aggregate + all-reduce) + pass 2 (LOO systems) + the jn+1 solves
+        out["config"]["end_to_end"] = {"pass1_s": round(ms_per_step / 1e3, 4), "pass2_s": round(t_pass2, 4), "solve_s": round(t_solve, 4),
+                                       "snps_per_s": M / (ms_per_step / 1e3 + t_pass2 + t_solve)}
         out["config"]["sigma_total"] = [float(v) for v in sig[-1]]
         out["config"]["sigma_se"] = [float(v) for v in est.jackknife_se(np.array(sig[:-1]), jn)]
 

@@ -150,6 +150,28 @@ int pyrhe_engine_block_stats(pyrhe_engine_t* e, const uint8_t* packed, int64_t n
 int pyrhe_sum_blocks(const float* blocks, int n_blocks, int64_t block_stride, int64_t n, double* out, void* stream);
 
 /*
+ * Leave-one-out inner products for the normal equations: the Gram loops of Base.setup_lhs_rhs_jackknife
+ * (pyrhe/src/base/base.py:568-628: <XXz_a, XXz_b>, <XXUz_a, UXXz_b>, <XXz_a, U z>) and GENIE.b_trace_calculation
+ * (pyrhe/src/models/genie/genie.py:84-94: <XXz_a, z>), on the device, for a whole batch of jackknife blocks per call.
+ * A row is described, not materialised:
+ *     v[idx] = tot[idx] - blk[z * blk_batch_stride + idx] * mul[idx % period],     idx < n_sub * period
+ * tot (device float64, the whole-data accumulator), blk (device float32, the stored sketch of batch element z; the
+ * product with mul is rounded in float32 like the reference's elem_mul, streaming_genie.py:39-41) and mul (device
+ * float32 [period]) may each be NULL (tot or blk must be given).  The arrays x / y themselves are HOST arrays.
+ *     out[z][a][b] = sum_idx x_a[idx] * y_b[idx]        float64, device, [n_batch][nx][ny]
+ * Sums are deterministic (fixed order).  period must be even, tot 16-byte and blk/mul 8-byte aligned.
+ * Asynchronous on `stream`; the engine owns the scratch, so calls on one engine must be on one stream.
+ */
+typedef struct pyrhe_row {
+    const double* tot;
+    const float* blk;
+    const float* mul;
+    int64_t blk_batch_stride; /* elements between the blk rows of consecutive batch elements */
+} pyrhe_row_t;
+int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, int nx, const pyrhe_row_t* y, int ny,
+                          int64_t period, int n_sub, int n_batch, double* out, void* stream);
+
+/*
  * Decode rows to dense float32 [n_rows][n_pad] (count of allele 2, NaN = missing): the bit-exact
  * decode contract of bed_reader.read + the reference's flip (base.py:338-356).  Test/diagnostic entry
  * point; independent of any engine.   Asynchronous on `stream`.

@@ -1258,6 +1258,7 @@ __global__ void synth_kernel(uint8_t* __restrict__ packed, int64_t n_rows, int64
 // ------------------------------------------------------------------------------------------------
 // engine
 // ------------------------------------------------------------------------------------------------
+struct BlkRowDev;
 struct pyrhe_engine {
     int device = 0;
     int64_t n_keep = 0, pitch = 0, n_pad = 0, max_entries = 0, sub_snps = 0;
@@ -1288,6 +1289,10 @@ struct pyrhe_engine {
     int32_t* rows32 = nullptr;
     float* partial = nullptr;     // [max 3][n_sketch<=32][n_pad] K-split partial sketches (allocated on first use)
     size_t partial_bytes = 0;
+    double* dots_partial = nullptr;   // workgroup partials of pyrhe_engine_loo_dots (allocated on first use)
+    size_t dots_partial_bytes = 0;
+    BlkRowDev* dots_desc = nullptr;   // row descriptors of its matrix-core path
+    size_t dots_desc_rows = 0;
     // Two workspace sets + two internal streams: GEMM 1 (+ mid) of sub-block g+1 runs on stream A while GEMM 2 of
     // sub-block g runs on stream B -- a DRAM-pattern-bound kernel beside an instruction-bound one.  The members
     // above alias the set in use (kernel arguments are captured by value at launch).
@@ -1436,7 +1441,7 @@ extern "C" int pyrhe_engine_destroy(pyrhe_engine_t* e) {
     if (e->evIn) (void)hipEventDestroy(e->evIn);
     if (e->evDoneA) (void)hipEventDestroy(e->evDoneA);
     if (e->evDoneB) (void)hipEventDestroy(e->evDoneB);
-    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->partial); hipFree(e->dom_ws);
+    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->partial); hipFree(e->dom_ws); hipFree(e->dots_partial); hipFree(e->dots_desc);
     delete e;
     return PYRHE_OK;
 }
@@ -1580,6 +1585,271 @@ __global__ void sum_blocks_kernel(const float* __restrict__ blocks, int n_blocks
         double* o = out + 4 * i;
         o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Leave-one-out inner products (the Gram loops of Base.setup_lhs_rhs_jackknife, base.py:568-628, and GENIE's stochastic
+// trace, genie.py:84-94).  A logical row is  v[idx] = tot[idx] - blk[z * stride + idx] * mul[idx % period]  (tot float64,
+// blk float32 = one stored block sketch of batch element z, product with mul rounded in float32 like the reference's
+// elem_mul; any of the three may be absent).  out[z][a][b] = sum_idx x_a[idx] * y_b[idx] in float64 for a tile of up to
+// 8 x 8 rows.  HBM-bound streaming: every thread owns two consecutive idx (16-byte loads), 64 float64 accumulators;
+// blockIdx.y = sub-row (idx = y * period + i, no modulo), blockIdx.z = batch element.  Deterministic: the wave folds its
+// 64 x 64 accumulators with a transposing butterfly (63 exchanges instead of 384), waves meet in LDS, workgroups write
+// partials that loo_dots_reduce_kernel adds in a fixed order.
+// ------------------------------------------------------------------------------------------------
+struct DotRows {
+    const double* tot[8];
+    const float* blk[8];
+    const float* mul[8];
+    long long stride[8];
+};
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask);
+    hi = __shfl_xor(hi, mask);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void dot_rows_load(const DotRows& R, int n, int64_t idx, int64_t i, int z, double (&v0)[8], double (&v1)[8]) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        double x0 = 0.0, x1 = 0.0;
+        if (a < n) {
+            if (R.tot[a]) {
+                const double2 t = *reinterpret_cast<const double2*>(R.tot[a] + idx);
+                x0 = t.x; x1 = t.y;
+            }
+            if (R.blk[a]) {
+                float2 b = *reinterpret_cast<const float2*>(R.blk[a] + (int64_t)z * R.stride[a] + idx);
+                if (R.mul[a]) {
+                    const float2 m = *reinterpret_cast<const float2*>(R.mul[a] + i);
+                    b.x *= m.x; b.y *= m.y;
+                }
+                x0 -= (double)b.x; x1 -= (double)b.y;
+            }
+        }
+        v0[a] = x0; v1[a] = x1;
+    }
+}
+
+__global__ __launch_bounds__(256) void loo_dots_kernel(const DotRows X, int nx, const DotRows Y, int ny, int64_t period,
+                                                       double* __restrict__ partial) {
+    __shared__ double s_red[4][64];
+    const int z = blockIdx.z;
+    const int64_t base = (int64_t)blockIdx.y * period;
+    double acc[64];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) acc[t] = 0.0;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; i < period; i += (int64_t)gridDim.x * 512) {
+        double x0[8], x1[8], y0[8], y1[8];
+        dot_rows_load(X, nx, base + i, i, z, x0, x1);
+        dot_rows_load(Y, ny, base + i, i, z, y0, y1);
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[a * 8 + b] = fma(x1[a], y1[b], fma(x0[a], y0[b], acc[a * 8 + b]));
+    }
+    // transposing butterfly: after the step with mask m a lane keeps the half of its accumulators selected by its bit m
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int t = 0; t < m; ++t) {
+            const double keep = up ? acc[t + m] : acc[t];
+            const double send = up ? acc[t] : acc[t + m];
+            acc[t] = keep + shfl_xor_f64(send, m);
+        }
+    }
+    s_red[wave][lane] = acc[0];            // lane L holds accumulator index L = a * 8 + b
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const double v = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+        const int64_t wg = ((int64_t)z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[wg * 64 + threadIdx.x] = v;
+    }
+}
+
+// out[z][a0 + a][b0 + b] = sum over the n_part workgroup partials of batch element z (fixed order)
+__global__ void loo_dots_reduce_kernel(const double* __restrict__ partial, int n_part, int n_batch, int nx_t, int ny_t,
+                                       int a0, int b0, int nx, int ny, double* __restrict__ out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int z = gid >> 6, t = gid & 63, a = t >> 3, b = t & 7;
+    if (z >= n_batch || a >= nx_t || b >= ny_t) return;
+    const double* p = partial + (int64_t)z * n_part * 64 + t;
+    double s = 0.0;
+    for (int w = 0; w < n_part; ++w) s += p[(int64_t)w * 64];
+    out[((int64_t)z * nx + a0 + a) * ny + b0 + b] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path of the leave-one-out inner products: MANY float32 block rows against a FEW fixed float64 rows
+// (projections of the stored block sketches onto the covariates, <block XXz, whole-data XXz>, <block XXUz, UXXz>,
+// <block XXz, z>): a tall-skinny GEMM on the float64 matrix cores.  Row r = (batch element z, descriptor a) is the A
+// operand of v_mfma_f64_16x16x4_f64 (lane (n, q): row n of the tile, k = q), the fixed rows are the B operand (lane
+// (n, q): column n, k = q); the contraction index is free to permute, so a lane reads 8 consecutive elements
+// idx = i0 + 8 q + j and MFMA j contracts element j of every lane group.  A wave keeps 4 row tiles (64 rows) x 16
+// columns in 32 accumulator registers, so the fixed rows are re-read once per 64 block rows instead of once per 8 as
+// in the register-tiled generic kernel.  Rows evaluate to -blk * mul (the block part of a leave-one-out row); the sign
+// is restored by the reduction.  Rows / columns past the end compute garbage that the reduction never reads.
+// ------------------------------------------------------------------------------------------------
+struct BlkRowDev {
+    const float* blk;
+    const float* mul;
+    long long stride;
+};
+struct FixedRows {
+    const double* p[16];
+};
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void blk_fixed_dots_kernel(const BlkRowDev* __restrict__ rows, int nx, int n_rows,
+                                                             const FixedRows Y, int ny, int64_t period, int chunk,
+                                                             int n_chunks, double* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int cx = blockIdx.x * 4 + wave;
+    if (cx >= n_chunks) return;                       // no barriers below
+    const int sub = blockIdx.y, rg = blockIdx.z;
+    const int64_t i_begin = (int64_t)cx * chunk;
+    const int64_t i_end = min(i_begin + (int64_t)chunk, period);
+    const float* ap[4];
+    const float* mp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int r = rg * 64 + t * 16 + n;
+        if (r >= n_rows) r = 0;
+        const int z = r / nx, a = r - z * nx;
+        const BlkRowDev d = rows[a];
+        ap[t] = d.blk + (int64_t)z * d.stride + (int64_t)sub * period;
+        mp[t] = d.mul;
+    }
+    const double* bp = Y.p[0];
+#pragma unroll
+    for (int c = 1; c < 16; ++c)
+        if (n == c && c < ny) bp = Y.p[c];
+    bp += (int64_t)sub * period;
+    double4v acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (double4v){0.0, 0.0, 0.0, 0.0};
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += 32) {
+        const int64_t off = i0 + 8 * q;
+        double b[8];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const double2 v = *reinterpret_cast<const double2*>(bp + off + 2 * h);
+            b[2 * h] = v.x; b[2 * h + 1] = v.y;
+        }
+        float a[4][8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 v0 = *reinterpret_cast<const float4*>(ap[t] + off);
+            const float4 v1 = *reinterpret_cast<const float4*>(ap[t] + off + 4);
+            float4 m0 = {1.f, 1.f, 1.f, 1.f}, m1 = {1.f, 1.f, 1.f, 1.f};
+            if (mp[t]) {
+                m0 = *reinterpret_cast<const float4*>(mp[t] + off);
+                m1 = *reinterpret_cast<const float4*>(mp[t] + off + 4);
+            }
+            a[t][0] = v0.x * m0.x; a[t][1] = v0.y * m0.y; a[t][2] = v0.z * m0.z; a[t][3] = v0.w * m0.w;
+            a[t][4] = v1.x * m1.x; a[t][5] = v1.y * m1.y; a[t][6] = v1.z * m1.z; a[t][7] = v1.w * m1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[t][j], b[j], acc[t], 0, 0, 0);
+    }
+    // D: col = n (fixed row), row = q + 4 reg (row of the tile)
+    double* dst = partial + (((int64_t)rg * gridDim.y + sub) * n_chunks + cx) * 1024;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) dst[(t * 16 + q + 4 * reg) * 16 + n] = acc[t][reg];
+}
+
+// out[z][a][b0 + b] = - sum over (sub-row, chunk) partials of row r = z * nx + a
+__global__ void blk_fixed_reduce_kernel(const double* __restrict__ partial, int n_part, int n_rows, int nyt, int b0, int ny,
+                                        double* __restrict__ out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = gid >> 4, b = gid & 15;
+    if (r >= n_rows || b >= nyt) return;
+    const double* p = partial + ((int64_t)(r >> 6) * n_part) * 1024 + (r & 63) * 16 + b;
+    double s = 0.0;
+    for (int w = 0; w < n_part; ++w) s += p[(int64_t)w * 1024];
+    out[(int64_t)r * ny + b0 + b] = -s;
+}
+
+// Self Gram of the block rows of every batch element, out[z][a][b] = <blk_a, blk_b> (the bb term of the expanded
+// leave-one-out Gram): with the float64 16x16x4 matrix instruction the A operand (lane (n, q): row n, k = q) and the B
+// operand (column n, k = q) of a tile against itself are the SAME register, so every element is loaded once.  A tile
+// holds floor(16 / nx) batch elements x nx rows; the products across different batch elements of a tile are computed
+// and never read.
+__global__ __launch_bounds__(256) void blk_self_gram_kernel(const BlkRowDev* __restrict__ rows, int nx, int n_batch,
+                                                            int64_t period, int chunk, int n_chunks,
+                                                            double* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int cx = blockIdx.x * 4 + wave;
+    if (cx >= n_chunks) return;
+    const int sub = blockIdx.y, tg = blockIdx.z;
+    const int zt = 16 / nx;                          // batch elements per tile
+    const int64_t i_begin = (int64_t)cx * chunk;
+    const int64_t i_end = min(i_begin + (int64_t)chunk, period);
+    const float* ap[4];
+    const float* mp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int z = (tg * 4 + t) * zt + n / nx, a = n % nx;
+        if (n >= zt * nx || z >= n_batch) { z = 0; a = 0; }
+        const BlkRowDev d = rows[a];
+        ap[t] = d.blk + (int64_t)z * d.stride + (int64_t)sub * period;
+        mp[t] = d.mul;
+    }
+    double4v acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (double4v){0.0, 0.0, 0.0, 0.0};
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += 32) {
+        const int64_t off = i0 + 8 * q;
+        float a[4][8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 v0 = *reinterpret_cast<const float4*>(ap[t] + off);
+            const float4 v1 = *reinterpret_cast<const float4*>(ap[t] + off + 4);
+            float4 m0 = {1.f, 1.f, 1.f, 1.f}, m1 = {1.f, 1.f, 1.f, 1.f};
+            if (mp[t]) {
+                m0 = *reinterpret_cast<const float4*>(mp[t] + off);
+                m1 = *reinterpret_cast<const float4*>(mp[t] + off + 4);
+            }
+            a[t][0] = v0.x * m0.x; a[t][1] = v0.y * m0.y; a[t][2] = v0.z * m0.z; a[t][3] = v0.w * m0.w;
+            a[t][4] = v1.x * m1.x; a[t][5] = v1.y * m1.y; a[t][6] = v1.z * m1.z; a[t][7] = v1.w * m1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double v = (double)a[t][j];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc[t], 0, 0, 0);
+            }
+    }
+    double* dst = partial + (((int64_t)tg * gridDim.y + sub) * n_chunks + cx) * 1024;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) dst[(t * 16 + q + 4 * reg) * 16 + n] = acc[t][reg];
+}
+
+__global__ void blk_self_gram_reduce_kernel(const double* __restrict__ partial, int n_part, int nx, int n_batch,
+                                            double* __restrict__ out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int z = gid / (nx * nx), ab = gid % (nx * nx), a = ab / nx, b = ab % nx;
+    if (z >= n_batch) return;
+    const int zt = 16 / nx, tile = z / zt, zl = z % zt;
+    const int tg = tile >> 2, t = tile & 3;
+    const double* p = partial + ((int64_t)tg * n_part) * 1024 + (t * 16 + zl * nx + a) * 16 + zl * nx + b;
+    double s = 0.0;
+    for (int w = 0; w < n_part; ++w) s += p[(int64_t)w * 1024];
+    out[gid] = s;
 }
 
 __global__ void add_norm_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, int accumulate) {
@@ -1992,6 +2262,133 @@ extern "C" int pyrhe_sum_blocks(const float* blocks, int n_blocks, int64_t block
     if (n <= 0 || n % 4 || block_stride % 4) return fail(PYRHE_EINVAL, "n and block_stride must be positive multiples of 4");
     if (n_blocks < 0) return fail(PYRHE_EINVAL, "n_blocks negative");
     sum_blocks_kernel<<<4096, 256, 0, (hipStream_t)stream_>>>(blocks, n_blocks, block_stride, n / 4, out);
+    HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
+extern "C" int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, int nx, const pyrhe_row_t* y, int ny,
+                                     int64_t period, int n_sub, int n_batch, double* out, void* stream_) {
+    if (!e || !x || !y || !out) return fail(PYRHE_EINVAL, "NULL argument");
+    if (nx < 1 || ny < 1) return fail(PYRHE_EINVAL, "nx and ny must be >= 1");
+    if (period <= 0 || period % 2) return fail(PYRHE_EINVAL, "period (%lld) must be positive and even", (long long)period);
+    if (n_sub < 1 || n_sub > 65535 || n_batch < 1 || n_batch > 65535) return fail(PYRHE_EINVAL, "n_sub / n_batch outside 1..65535");
+    for (int pass = 0; pass < 2; ++pass) {
+        const pyrhe_row_t* r = pass ? y : x;
+        for (int a = 0; a < (pass ? ny : nx); ++a) {
+            if (!r[a].tot && !r[a].blk) return fail(PYRHE_EINVAL, "%c row %d has neither tot nor blk", pass ? 'y' : 'x', a);
+            if (r[a].mul && !r[a].blk) return fail(PYRHE_EINVAL, "%c row %d: mul without blk", pass ? 'y' : 'x', a);
+            if (((uintptr_t)r[a].tot & 15) || ((uintptr_t)r[a].blk & 7) || ((uintptr_t)r[a].mul & 7) || (r[a].blk_batch_stride & 1))
+                return fail(PYRHE_EINVAL, "%c row %d is not 16-byte (tot) / 8-byte (blk, mul, stride) aligned", pass ? 'y' : 'x', a);
+        }
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipSetDevice(e->device));
+    auto ensure_partial = [&](size_t need) -> int {
+        if (e->dots_partial_bytes < need) {
+            if (e->dots_partial) {
+                HIPCHK(hipDeviceSynchronize());       // earlier launches may still read the old scratch
+                HIPCHK(hipFree(e->dots_partial));
+            }
+            HIPCHK(hipMalloc(&e->dots_partial, need));
+            e->dots_partial_bytes = need;
+        }
+        return PYRHE_OK;
+    };
+    // ---- block rows (float32) against fixed rows (float64): the matrix-core path
+    bool fast = period % 32 == 0 && (int64_t)nx * n_batch < (1 << 30);
+    for (int a = 0; a < nx && fast; ++a) fast = !x[a].tot && x[a].blk && (((uintptr_t)x[a].blk | (uintptr_t)x[a].mul) & 15) == 0 && x[a].blk_batch_stride % 4 == 0;
+    for (int b = 0; b < ny && fast; ++b) fast = y[b].tot && !y[b].blk;
+    static const bool no_fast = getenv("PYRHE_DOTS_GENERIC") && atoi(getenv("PYRHE_DOTS_GENERIC")) != 0;
+    // ---- block rows against themselves (x and y are the same block-only rows): the self-Gram path
+    bool self = period % 32 == 0 && nx == ny && nx <= 16;
+    for (int a = 0; a < nx && self; ++a)
+        self = !x[a].tot && x[a].blk && x[a].blk == y[a].blk && x[a].mul == y[a].mul && !y[a].tot &&
+               x[a].blk_batch_stride == y[a].blk_batch_stride && (((uintptr_t)x[a].blk | (uintptr_t)x[a].mul) & 15) == 0 &&
+               x[a].blk_batch_stride % 4 == 0;
+    auto upload_desc = [&]() -> int {
+        if (e->dots_desc_rows < (size_t)nx) {
+            if (e->dots_desc) {
+                HIPCHK(hipDeviceSynchronize());
+                HIPCHK(hipFree(e->dots_desc));
+            }
+            HIPCHK(hipMalloc(&e->dots_desc, (size_t)nx * sizeof(BlkRowDev)));
+            e->dots_desc_rows = nx;
+        }
+        std::vector<BlkRowDev> desc(nx);
+        for (int a = 0; a < nx; ++a) desc[a] = {x[a].blk, x[a].mul, (long long)x[a].blk_batch_stride};
+        // pageable source: the runtime stages the bytes before returning, so `desc` may die at the end of this call
+        HIPCHK(hipMemcpyAsync(e->dots_desc, desc.data(), (size_t)nx * sizeof(BlkRowDev), hipMemcpyHostToDevice, stream));
+        return PYRHE_OK;
+    };
+    if (self && !no_fast) {
+        int rc = upload_desc();
+        if (rc) return rc;
+        const int zt = 16 / nx, tiles = (n_batch + zt - 1) / zt, tgs = (tiles + 3) / 4;
+        int64_t n_chunks = std::max<int64_t>(1, 4096 / ((int64_t)tgs * n_sub));
+        n_chunks = std::min<int64_t>(n_chunks, std::max<int64_t>(1, period / 256));
+        const int chunk = (int)(((period + n_chunks - 1) / n_chunks + 31) / 32 * 32);
+        n_chunks = (period + chunk - 1) / chunk;
+        const int n_part = (int)n_chunks * n_sub;
+        rc = ensure_partial((size_t)tgs * n_part * 1024 * sizeof(double));
+        if (rc) return rc;
+        dim3 grid((unsigned)((n_chunks + 3) / 4), n_sub, tgs);
+        blk_self_gram_kernel<<<grid, 256, 0, stream>>>(e->dots_desc, nx, n_batch, period, chunk, (int)n_chunks, e->dots_partial);
+        blk_self_gram_reduce_kernel<<<(n_batch * nx * nx + 255) / 256, 256, 0, stream>>>(e->dots_partial, n_part, nx, n_batch, out);
+        HIPCHK(hipGetLastError());
+        return PYRHE_OK;
+    }
+    if (fast && !no_fast) {
+        {
+            const int rc = upload_desc();
+            if (rc) return rc;
+        }
+        const int n_rows = nx * n_batch;
+        const int rgs = (n_rows + 63) / 64;
+        int64_t n_chunks = std::max<int64_t>(1, 4096 / ((int64_t)rgs * n_sub));
+        n_chunks = std::min<int64_t>(n_chunks, std::max<int64_t>(1, period / 256));
+        const int chunk = (int)(((period + n_chunks - 1) / n_chunks + 31) / 32 * 32);
+        n_chunks = (period + chunk - 1) / chunk;
+        const int n_part = (int)n_chunks * n_sub;
+        const int rc = ensure_partial((size_t)rgs * n_part * 1024 * sizeof(double));
+        if (rc) return rc;
+        for (int b0 = 0; b0 < ny; b0 += 16) {
+            const int nyt = std::min(16, ny - b0);
+            FixedRows Y;
+            for (int c = 0; c < 16; ++c) Y.p[c] = c < nyt ? y[b0 + c].tot : nullptr;
+            dim3 grid((unsigned)((n_chunks + 3) / 4), n_sub, rgs);
+            blk_fixed_dots_kernel<<<grid, 256, 0, stream>>>(e->dots_desc, nx, n_rows, Y, nyt, period, chunk, (int)n_chunks, e->dots_partial);
+            blk_fixed_reduce_kernel<<<(n_rows * 16 + 255) / 256, 256, 0, stream>>>(e->dots_partial, n_part, n_rows, nyt, b0, ny, out);
+        }
+        HIPCHK(hipGetLastError());
+        return PYRHE_OK;
+    }
+    // enough workgroups to fill the chip, each with >= 4 iterations where the data allows
+    const int64_t want = (2048 + (int64_t)n_sub * n_batch - 1) / ((int64_t)n_sub * n_batch);
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(want, 4), (period + 2047) / 2048));
+    const int n_part = gx * n_sub;
+    {
+        const int rc = ensure_partial((size_t)n_part * n_batch * 64 * sizeof(double));
+        if (rc) return rc;
+    }
+    auto tile = [](const pyrhe_row_t* r, int n0, int n, DotRows& d) {
+        for (int a = 0; a < 8; ++a) {
+            const bool on = a < n;
+            d.tot[a] = on ? r[n0 + a].tot : nullptr;
+            d.blk[a] = on ? r[n0 + a].blk : nullptr;
+            d.mul[a] = on ? r[n0 + a].mul : nullptr;
+            d.stride[a] = on ? r[n0 + a].blk_batch_stride : 0;
+        }
+    };
+    for (int a0 = 0; a0 < nx; a0 += 8)
+        for (int b0 = 0; b0 < ny; b0 += 8) {
+            const int nxt = std::min(8, nx - a0), nyt = std::min(8, ny - b0);
+            DotRows X, Y;
+            tile(x, a0, nxt, X);
+            tile(y, b0, nyt, Y);
+            dim3 grid(gx, n_sub, n_batch);
+            loo_dots_kernel<<<grid, 256, 0, stream>>>(X, nxt, Y, nyt, period, e->dots_partial);
+            loo_dots_reduce_kernel<<<(n_batch * 64 + 255) / 256, 256, 0, stream>>>(e->dots_partial, n_part, n_batch, nxt, nyt, a0, b0, nx, ny, out);
+        }
     HIPCHK(hipGetLastError());
     return PYRHE_OK;
 }

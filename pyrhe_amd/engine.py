@@ -42,6 +42,7 @@ SYMBOLS = {
     "pyrhe_engine_set_pipeline": (_i32, [_vp, _i32]),
     "pyrhe_decode_rows": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "pyrhe_sum_blocks": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
+    "pyrhe_engine_loo_dots": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "pyrhe_synth_genotypes": (_i32, [_vp, _i64, _i64, _i64, _u64, _i64, _vp]),
     "pyrhe_engine_info": (_i64, [_vp, _i32]),
     "pyrhe_engine_profile": (_i32, [_vp, _i32]),
@@ -69,6 +70,21 @@ def load_library():
 
 class SketchError(RuntimeError):
     pass
+
+
+class _RowStruct(C.Structure):      # pyrhe_row_t (include/pyrhe_sketch.h)
+    _fields_ = [("tot", _vp), ("blk", _vp), ("mul", _vp), ("blk_batch_stride", _i64)]
+
+
+class Row:
+    """One logical row of ``pyrhe_engine_loo_dots``: ``tot - blk[z] * mul``.  ``tot`` float64 ``[n_sub * period]``
+    view, ``blk`` float32 view of batch element 0 with ``stride`` elements to the next one, ``mul`` float32 ``[period]``."""
+    __slots__ = ("tot", "blk", "mul", "stride")
+
+    def __init__(self, tot=None, blk=None, mul=None, stride=0):
+        for t, dt in ((tot, torch.float64), (blk, torch.float32), (mul, torch.float32)):
+            assert t is None or (t.dtype == dt and t.is_contiguous())
+        self.tot, self.blk, self.mul, self.stride = tot, blk, mul, int(stride)
 
 
 def _check(code: int, what: str):
@@ -291,6 +307,24 @@ class SketchEngine:
             _check(self.lib.pyrhe_engine_block_stats(self._h, _ptr(packed), m, _ptr(s), _ptr(nm), _stream_ptr(self.device)),
                    "pyrhe_engine_block_stats")
         return s, nm
+
+    def loo_dots(self, x: Sequence[Row], y: Sequence[Row], period: int, n_sub: int, n_batch: int = 1) -> torch.Tensor:
+        """``out[z, a, b] = sum_idx x_a[idx] y_b[idx]`` over ``n_sub * period`` elements, float64 ``[n_batch, nx, ny]``."""
+        def pack(rows):
+            arr = (_RowStruct * len(rows))()
+            for i, r in enumerate(rows):
+                arr[i].tot = None if r.tot is None else r.tot.data_ptr()
+                arr[i].blk = None if r.blk is None else r.blk.data_ptr()
+                arr[i].mul = None if r.mul is None else r.mul.data_ptr()
+                arr[i].blk_batch_stride = r.stride
+            return arr
+        out = torch.empty((n_batch, len(x), len(y)), dtype=torch.float64, device=self.device)
+        xa, ya = pack(x), pack(y)
+        with torch.cuda.device(self.device):
+            _check(self.lib.pyrhe_engine_loo_dots(self._h, C.cast(xa, _vp), len(x), C.cast(ya, _vp), len(y), int(period),
+                                                  int(n_sub), int(n_batch), _ptr(out), _stream_ptr(self.device)),
+                   "pyrhe_engine_loo_dots")
+        return out
 
     def profile(self, enable: bool):
         _check(self.lib.pyrhe_engine_profile(self._h, 1 if enable else 0), "pyrhe_engine_profile")

@@ -166,9 +166,12 @@ class SketchRunner:
             self.Q64 = torch.from_numpy(self.Q).to(self.device)
             self.Q32 = self.Q64.to(torch.float32)
             self.UZ64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.UZ.T)))  # [k, n_pad]
+            self.WT64 = self.W64.T.contiguous()                                              # [c, n_pad]
         self.Z64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.Z.T)))        # [k, n_pad] f64
         if self.env is not None:
             self.env_pad = self._pad_cols(torch.from_numpy(self.env[None, :]))[0]            # [n_pad] f64
+            self.env32 = self.env_pad.to(torch.float32)
+        self.pass2_impl = "hip"       # "torch": materialised cross-check path (tests)
         self._entries_cache = {}
         self._stats = None
         self._check_missing = True
@@ -486,12 +489,46 @@ class SketchRunner:
                 D = torch.cat([D, Dn], dim=0)
             return A, C, D, r
 
+        if self.pass2_impl == "torch":
+            return self._pass2_torch(M, yy, tot_A, tot_C, D_tot, tot_r, nxe, with_nxe)
+        # ---- on-device assembly: every inner product of a slot comes from pyrhe_engine_loo_dots, whole batches of
+        # blocks per call; only [batch, ne, ne]-sized results reach the host
+        tots = (tot_A, tot_C, D_tot, tot_r)
+        local = []
+        js = list(range(self.j0, self.j1))
+        if jn == 1 and js == [0]:                               # base.py:654-655: the only slot is the whole-data one
+            js = []
+        if js and not self.recompute_pass2:
+            store = (self.blocks_sk, self.blocks_nm, self.blocks_skd, self.blocks_nmd)
+            Ts, qs = self._loo_systems(tots, nxe, store, len(js), M[js], yy)
+            local = [(j, Ts[i], qs[i]) for i, j in enumerate(js)]
+        else:
+            for j in js:
+                sk, nm, skd, nmd = self._resketch(j)
+                store = ([t[None] for t in sk], [t[None] for t in nm],
+                         None if skd is None else [t[None] for t in skd], None if nmd is None else [t[None] for t in nmd])
+                Ts, qs = self._loo_systems(tots, nxe, store, 1, M[j:j + 1], yy)
+                local.append((j, Ts[0], qs[0]))
+        Ts, qs = self._loo_systems(tots, nxe, None, 1, M[jn:jn + 1], yy)
+        T_tot, q_tot = Ts[0], qs[0]
+        if jn == 1 and self.j0 == 0 and self.j1 == 1:
+            local = [(0, T_tot, q_tot)]
+        if self.world > 1:
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, local, group=self.group)
+            local = [item for part in gathered for item in part]
+        local.sort(key=lambda t: t[0])
+        Ts = np.stack([t[1] for t in local] + [T_tot])
+        qs = np.stack([t[2] for t in local] + [q_tot])
+        return Systems(Ts, qs, M)
+
+    def _pass2_torch(self, M, yy, tot_A, tot_C, D_tot, tot_r, nxe, with_nxe):
+        """The same systems from materialised leave-one-out arrays and torch reductions: slow (degenerate GEMM shapes),
+        kept as an independent cross-check of the on-device assembly (tests set ``pass2_impl = "torch"``)."""
+        jn, use_cov = self.plan.n_jack, self.cov is not None
         local = []
         for jl_i, j in enumerate(range(self.j0, self.j1)):
-            if self.recompute_pass2:
-                stored = self._resketch(j)
-            else:
-                stored = self._stored_block(jl_i)
+            stored = self._resketch(j) if self.recompute_pass2 else self._stored_block(jl_i)
             slot = jn if (jn == 1 and j == 0) else j          # base.py:654-655
             if slot == jn:
                 T, q = self._system(*with_nxe(tot_A, tot_C, D_tot, tot_r), M[jn], yy)
@@ -509,9 +546,143 @@ class SketchRunner:
             dist.all_gather_object(gathered, local, group=self.group)
             local = [item for part in gathered for item in part]
         local.sort(key=lambda t: t[0])
-        Ts = np.stack([t[1] for t in local] + [T_tot])
-        qs = np.stack([t[2] for t in local] + [q_tot])
-        return Systems(Ts, qs, M)
+        return Systems(np.stack([t[1] for t in local] + [T_tot]), np.stack([t[2] for t in local] + [q_tot]), M)
+
+    # ---- on-device normal equations ---------------------------------------------
+    def _loo_rows(self, tot, store, group, egroup, nxe_row):
+        """Row descriptors of the ne estimates of one accumulator family (XXz: group "Z"/"eZ", XXUz: "UZ"/"eUZ"):
+        whole-data slot minus the stored block sketch (``store`` None: whole-data slot alone)."""
+        from .engine import Row
+        nb, k = self.plan.n_bin, self.k
+        sk, skd = (store[0], store[2]) if store is not None else (None, None)
+
+        def view(lst, name, b):
+            p_, c0 = self.loc[name]
+            t = lst[p_]                                            # [batch, nb, n_sketch, n_pad] float32
+            return t[0, b, c0:c0 + k], t.stride(0)
+        rows = []
+        for a in range(tot.shape[0]):
+            blk, stride, mul = None, 0, None
+            if sk is not None:
+                if a < nb:
+                    blk, stride = view(sk, group, a)
+                elif self.dom:
+                    blk, stride = view(skd, group, a - nb)
+                else:
+                    blk, stride = view(sk, egroup, a - nb)
+                    mul = self.env32
+            rows.append(Row(tot[a], blk, mul, stride))
+        if nxe_row is not None:
+            rows.append(Row(nxe_row))
+        return rows
+
+    def _sub_rows(self, rows):
+        """The k sub-rows (one probe vector each, length n_pad) of every row, for projections onto the covariates."""
+        from .engine import Row
+        out = []
+        for r in rows:
+            for s_ in range(self.k):
+                out.append(Row(None if r.tot is None else r.tot[s_], None if r.blk is None else r.blk[s_], r.mul, r.stride))
+        return out
+
+    def _lin_dots(self, x, y, n_sub, batch):
+        """<x_a, y_b> for leave-one-out rows x against FIXED rows y, split by linearity into the whole-data part (read
+        once, not once per block) and the block part (float32 rows only): [batch, len(x), len(y)], and the block part
+        alone (the inner products of the stored block sketches, sign restored)."""
+        from .engine import Row
+        tot_rows = [None if r.tot is None else Row(r.tot) for r in x]
+        blk_rows = [None if r.blk is None else Row(None, r.blk, r.mul, r.stride) for r in x]
+        t = self._dots(tot_rows, y, n_sub, 1)
+        b = self._dots(blk_rows, y, n_sub, batch)                  # rows evaluate to -blk
+        return t + b, -b
+
+    def _dots(self, x, y, n_sub, batch):
+        """loo_dots with None rows (exact zeros) filtered out; float64 numpy [batch, len(x), len(y)]."""
+        xi = [i for i, r in enumerate(x) if r is not None]
+        yi = [i for i, r in enumerate(y) if r is not None]
+        out = np.zeros((batch, len(x), len(y)))
+        if xi and yi:
+            res = self.eng.loo_dots([x[i] for i in xi], [y[i] for i in yi], self.n_pad, n_sub, batch)
+            out[np.ix_(range(batch), xi, yi)] = res.cpu().numpy()
+        return out
+
+    def _loo_systems(self, tots, nxe, store, batch, M_rows, yy):
+        """Normal equations (base.py:568-628) of ``batch`` slots: whole-data accumulators minus the stored sketches of
+        ``batch`` blocks (``store`` None: the whole-data slot).  Returns T ``[batch, ne+1, ne+1]``, q ``[batch, ne+1]``."""
+        from .engine import Row
+        tot_A, tot_C, D_tot, tot_r = tots
+        ne, k, nb = self.n_est, self.k, self.plan.n_bin
+        use_cov = self.cov is not None
+        nA = nC = nD = None
+        if self.n_nxe:
+            nA = nxe[0][0]
+            if use_cov:      # only the last probe vector carries XXUz / UXXz (base.py:472-481, see pass2)
+                nC = torch.zeros_like(nxe[0][0]); nD = torch.zeros_like(nxe[0][0])
+                nC[k - 1] = nxe[1][0, k - 1]
+                nD[k - 1] = self._apply_U(nxe[0][0, k - 1], f32=True)
+        A = self._loo_rows(tot_A, store, "Z", "eZ", nA)
+        # <XXz_a, XXz_b> of the slot, expanded around the whole-data rows: (t - b)(t - b)^T = tt - bt - (bt)^T + bb.
+        # The whole-data rows are then read once per 64 block rows (matrix-core path) instead of once per block.
+        A_tot = [Row(r.tot) for r in A]
+        A_blk = [None if r.blk is None else Row(None, r.blk, r.mul, r.stride) for r in A]
+        fixed = list(A_tot)
+        if self.genie_model is not None:
+            fixed.append(Row(self.Z64))
+        if use_cov:
+            fixed.append(Row(self.UZ64))
+        bpart = self._dots(A_blk, fixed, k, batch)                # block rows evaluate to -blk: -<b_a, fixed>
+        g = self._dots(A_tot, fixed, k, 1) + bpart
+        gram = g[:, :, :ne] + np.transpose(bpart[:, :, :ne], (0, 2, 1)) + self._dots(A_blk, A_blk, k, batch)
+        col = ne
+        tz = tk = None
+        if self.genie_model is not None:
+            tz = g[:, :, col]; col += 1
+        if use_cov:
+            tk = g[:, :, col]
+            Cr = self._loo_rows(tot_C, store, "UZ", "eUZ", nC)
+            Dr = [Row(D_tot[a]) for a in range(D_tot.shape[0])] + ([Row(nD)] if nD is not None else [])
+            gCD = self._lin_dots(Cr, Dr, k, batch)[0]             # <XXUz_a (LOO), UXXz_b (whole data)>
+            Wr = [Row(self.WT64[m]) for m in range(self.WT64.shape[0])]
+            c = len(Wr)
+            # projections onto the covariates, P[z, a, s, m] = <row_a[s], W_m>; U = W Q W^T is applied through them:
+            # <U A_a, A_b> = sum_s PA[a,s] Q PA[b,s],  <C_a, U blkA_b> = sum_s PC[a,s] Q PblkA[b,s]  (base.py:583-593;
+            # UXXz_b = whole-data UXXz_b - U(block XXz_b), streaming_rhe.py:35-36)
+            PA, PbA = (t.reshape(batch, ne, k, c) for t in self._lin_dots(self._sub_rows(A), Wr, 1, batch))
+            PC = self._lin_dots(self._sub_rows(Cr), Wr, 1, batch)[0].reshape(batch, ne, k, c)
+            Q = self.Q
+            uaa = np.einsum("zasm,mn,zbsn->zab", PA, Q, PA)
+            cd = gCD - np.einsum("zasm,mn,zbsn->zab", PC, Q, PbA)
+            gram = gram + cd - 2.0 * uaa
+        # r = yXXy: whole-data minus block
+        r = tot_r.cpu().numpy()[None, :].repeat(batch, axis=0)
+        if store is not None:
+            py, cy = self.loc["y"]
+            parts = [store[1][py][:batch, :, cy]]
+            if self.dom:
+                parts.append(store[3][py][:batch, :, cy])
+            if self.n_gxe:
+                pe, ce = self.loc["ey"]
+                parts.append(store[1][pe][:batch, :, ce])
+            r = r - torch.cat(parts, dim=1).cpu().numpy()
+        if self.n_nxe:
+            r = np.concatenate([r, np.broadcast_to(nxe[2].cpu().numpy()[None, :], (batch, 1))], axis=1)
+        Mf = M_rows.astype(np.float64)                            # [batch, ne]
+        T = np.zeros((batch, ne + 1, ne + 1))
+        q = np.zeros((batch, ne + 1))
+        mm = Mf[:, :, None] * Mf[:, None, :]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            T[:, :ne, :ne] = np.where(mm != 0, gram / k / mm, 0.0)
+            tr = np.full((batch, ne), float(self.N))              # rhe.py:24-26
+            if self.genie_model is not None and ne > nb:
+                tr[:, nb:] = tz[:, nb:] / (k * Mf[:, nb:])         # stochastic trace of a GxE / NxE kernel (genie.py:85-89)
+            if use_cov:
+                tr = tr - tk / (k * Mf)                            # base.py:614-615
+            q[:, :ne] = np.where(Mf != 0, r / Mf, 0.0)
+        T[:, :ne, ne] = tr
+        T[:, ne, :ne] = tr
+        T[:, ne, ne] = self.N - (self.cov.shape[1] if use_cov else 0)
+        q[:, ne] = yy
+        return T, q
 
     def _stored_block(self, jl_i: int):
         sk, nm = [b[jl_i] for b in self.blocks_sk], [b[jl_i] for b in self.blocks_nm]

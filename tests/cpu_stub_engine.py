@@ -66,3 +66,20 @@ class CpuStubEngine:
                 out_sketch[b] = torch.from_numpy(sk).float()
                 out_norm[b] = torch.from_numpy(nm)
         return out_sketch, out_norm, None
+
+    def loo_dots(self, x, y, period, n_sub, n_batch=1):
+        """Oracle-side twin of pyrhe_engine_loo_dots (float64 torch on the CPU)."""
+        L = period * n_sub
+
+        def mat(rows):
+            out = torch.zeros((n_batch, len(rows), L), dtype=torch.float64)
+            for a, r in enumerate(rows):
+                if r.tot is not None:
+                    out[:, a] += r.tot.reshape(-1)[:L]
+                if r.blk is not None:
+                    b = r.blk.as_strided((n_batch, L), (r.stride, 1), r.blk.storage_offset())
+                    if r.mul is not None:
+                        b = (b.reshape(n_batch, n_sub, period) * r.mul).reshape(n_batch, L)
+                    out[:, a] -= b.double()
+            return out
+        return torch.einsum("zal,zbl->zab", mat(x), mat(y))

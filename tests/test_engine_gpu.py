@@ -192,3 +192,49 @@ def test_multibin_call_equals_one_call_per_bin(dev, precision, with_fill):
         assert (sk2[b] - 2 * s1[0]).abs().max().item() <= 2 * tol * scale, b
         assert torch.allclose(nm2[b], 2 * n1[0], rtol=tol, atol=0), b
     eng.close()
+
+
+@pytest.mark.parametrize("nx,ny,n_sub,batch", [(3, 5, 2, 7), (8, 8, 3, 5), (20, 11, 1, 9), (1, 1, 4, 33), (16, 17, 2, 3)])
+def test_loo_dots_paths_vs_float64_reference(dev, nx, ny, n_sub, batch):
+    """pyrhe_engine_loo_dots: the register-tiled generic kernel (mixed tot/blk rows), the matrix-core path (block rows
+    x fixed rows) and the self-Gram path (block rows x themselves) against a float64 torch evaluation of the row
+    definition  tot - blk[z] * mul."""
+    from pyrhe_amd import engine
+    from pyrhe_amd.engine import Row
+    period = 2048
+    L = period * n_sub
+    g = torch.Generator().manual_seed(nx * 100 + ny)
+    eng = engine.SketchEngine(4 * 256, 4 * 256, max_entries=32, device=dev)
+    store_c = torch.randn((batch, nx + 2, L), generator=g, dtype=torch.float32)       # block store: rows 1..nx used
+    store = store_c.to(dev)
+    mul_c = torch.randn(period, generator=g, dtype=torch.float32)
+    mul = mul_c.to(dev)
+    totx = torch.randn((nx, L), generator=g, dtype=torch.float64).to(dev)
+    toty = torch.randn((ny, L), generator=g, dtype=torch.float64).to(dev)
+
+    def blk_rows(with_tot):
+        rows = []
+        for a in range(nx):
+            r = Row(totx[a] if with_tot else None, store[0, 1 + a], mul if a % 2 else None, store.stride(0))
+            r_cpu_view = store_c[0, 1 + a]
+            rows.append((r, r_cpu_view))
+        return rows
+
+    def run(xp, yp):
+        x = [r for r, _ in xp]
+        y = [r for r, _ in yp]
+        got = eng.loo_dots(x, y, period, n_sub, batch).cpu()
+        from tests.cpu_stub_engine import CpuStubEngine
+        xc = [Row(None if r.tot is None else r.tot.cpu(), c, None if r.mul is None else mul_c, r.stride) for r, c in xp]
+        yc = [Row(None if r.tot is None else r.tot.cpu(), c, None if r.mul is None else mul_c, r.stride) for r, c in yp]
+        ref = CpuStubEngine.loo_dots(None, xc, yc, period, n_sub, batch)
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= 1e-12 * scale + 1e-9
+    fixed = [(Row(toty[b]), None) for b in range(ny)]
+    run(blk_rows(True), fixed)                       # generic: leave-one-out rows x fixed rows
+    run(blk_rows(False), fixed)                      # matrix-core: block rows x fixed rows
+    bx = blk_rows(False)
+    run(bx, bx)                                      # self Gram (nx <= 16) or generic tiles
+    lx = blk_rows(True)
+    run(lx, lx)                                      # generic: leave-one-out Gram
+    eng.close()
