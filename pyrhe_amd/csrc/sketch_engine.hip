@@ -1258,7 +1258,6 @@ __global__ void synth_kernel(uint8_t* __restrict__ packed, int64_t n_rows, int64
 // ------------------------------------------------------------------------------------------------
 // engine
 // ------------------------------------------------------------------------------------------------
-struct BlkRowDev;
 struct pyrhe_engine {
     int device = 0;
     int64_t n_keep = 0, pitch = 0, n_pad = 0, max_entries = 0, sub_snps = 0;
@@ -1291,8 +1290,6 @@ struct pyrhe_engine {
     size_t partial_bytes = 0;
     double* dots_partial = nullptr;   // workgroup partials of pyrhe_engine_loo_dots (allocated on first use)
     size_t dots_partial_bytes = 0;
-    BlkRowDev* dots_desc = nullptr;   // row descriptors of its matrix-core path
-    size_t dots_desc_rows = 0;
     // Two workspace sets + two internal streams: GEMM 1 (+ mid) of sub-block g+1 runs on stream A while GEMM 2 of
     // sub-block g runs on stream B -- a DRAM-pattern-bound kernel beside an instruction-bound one.  The members
     // above alias the set in use (kernel arguments are captured by value at launch).
@@ -1441,7 +1438,7 @@ extern "C" int pyrhe_engine_destroy(pyrhe_engine_t* e) {
     if (e->evIn) (void)hipEventDestroy(e->evIn);
     if (e->evDoneA) (void)hipEventDestroy(e->evDoneA);
     if (e->evDoneB) (void)hipEventDestroy(e->evDoneB);
-    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->partial); hipFree(e->dom_ws); hipFree(e->dots_partial); hipFree(e->dots_desc);
+    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->partial); hipFree(e->dom_ws); hipFree(e->dots_partial);
     delete e;
     return PYRHE_OK;
 }
@@ -1702,9 +1699,13 @@ struct BlkRowDev {
 struct FixedRows {
     const double* p[16];
 };
+constexpr int kDescMax = 128;          // block-row descriptors per launch, passed by value (3 KiB of kernel arguments:
+struct BlkRowTable {                   // no upload, nothing for the host to keep alive)
+    BlkRowDev r[kDescMax];
+};
 typedef double double4v __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void blk_fixed_dots_kernel(const BlkRowDev* __restrict__ rows, int nx, int n_rows,
+__global__ __launch_bounds__(256) void blk_fixed_dots_kernel(const BlkRowTable tab, int nx, int n_rows,
                                                              const FixedRows Y, int ny, int64_t period, int chunk,
                                                              int n_chunks, double* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1721,7 +1722,7 @@ __global__ __launch_bounds__(256) void blk_fixed_dots_kernel(const BlkRowDev* __
         int r = rg * 64 + t * 16 + n;
         if (r >= n_rows) r = 0;
         const int z = r / nx, a = r - z * nx;
-        const BlkRowDev d = rows[a];
+        const BlkRowDev d = tab.r[a];
         ap[t] = d.blk + (int64_t)z * d.stride + (int64_t)sub * period;
         mp[t] = d.mul;
     }
@@ -1769,15 +1770,16 @@ __global__ __launch_bounds__(256) void blk_fixed_dots_kernel(const BlkRowDev* __
 }
 
 // out[z][a][b0 + b] = - sum over (sub-row, chunk) partials of row r = z * nx + a
-__global__ void blk_fixed_reduce_kernel(const double* __restrict__ partial, int n_part, int n_rows, int nyt, int b0, int ny,
-                                        double* __restrict__ out) {
+__global__ void blk_fixed_reduce_kernel(const double* __restrict__ partial, int n_part, int n_rows, int nxc, int a0, int nx,
+                                        int nyt, int b0, int ny, double* __restrict__ out) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = gid >> 4, b = gid & 15;
+    const int r = gid >> 4, b = gid & 15;            // r = z * nxc + a over the nxc descriptors of this launch
     if (r >= n_rows || b >= nyt) return;
     const double* p = partial + ((int64_t)(r >> 6) * n_part) * 1024 + (r & 63) * 16 + b;
     double s = 0.0;
     for (int w = 0; w < n_part; ++w) s += p[(int64_t)w * 1024];
-    out[(int64_t)r * ny + b0 + b] = -s;
+    const int z = r / nxc, a = r - z * nxc;
+    out[((int64_t)z * nx + a0 + a) * ny + b0 + b] = -s;
 }
 
 // Self Gram of the block rows of every batch element, out[z][a][b] = <blk_a, blk_b> (the bb term of the expanded
@@ -1785,7 +1787,7 @@ __global__ void blk_fixed_reduce_kernel(const double* __restrict__ partial, int 
 // operand (column n, k = q) of a tile against itself are the SAME register, so every element is loaded once.  A tile
 // holds floor(16 / nx) batch elements x nx rows; the products across different batch elements of a tile are computed
 // and never read.
-__global__ __launch_bounds__(256) void blk_self_gram_kernel(const BlkRowDev* __restrict__ rows, int nx, int n_batch,
+__global__ __launch_bounds__(256) void blk_self_gram_kernel(const BlkRowTable tab, int nx, int n_batch,
                                                             int64_t period, int chunk, int n_chunks,
                                                             double* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1802,7 +1804,7 @@ __global__ __launch_bounds__(256) void blk_self_gram_kernel(const BlkRowDev* __r
     for (int t = 0; t < 4; ++t) {
         int z = (tg * 4 + t) * zt + n / nx, a = n % nx;
         if (n >= zt * nx || z >= n_batch) { z = 0; a = 0; }
-        const BlkRowDev d = rows[a];
+        const BlkRowDev d = tab.r[a];
         ap[t] = d.blk + (int64_t)z * d.stride + (int64_t)sub * period;
         mp[t] = d.mul;
     }
@@ -2305,59 +2307,49 @@ extern "C" int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, in
         self = !x[a].tot && x[a].blk && x[a].blk == y[a].blk && x[a].mul == y[a].mul && !y[a].tot &&
                x[a].blk_batch_stride == y[a].blk_batch_stride && (((uintptr_t)x[a].blk | (uintptr_t)x[a].mul) & 15) == 0 &&
                x[a].blk_batch_stride % 4 == 0;
-    auto upload_desc = [&]() -> int {
-        if (e->dots_desc_rows < (size_t)nx) {
-            if (e->dots_desc) {
-                HIPCHK(hipDeviceSynchronize());
-                HIPCHK(hipFree(e->dots_desc));
-            }
-            HIPCHK(hipMalloc(&e->dots_desc, (size_t)nx * sizeof(BlkRowDev)));
-            e->dots_desc_rows = nx;
-        }
-        std::vector<BlkRowDev> desc(nx);
-        for (int a = 0; a < nx; ++a) desc[a] = {x[a].blk, x[a].mul, (long long)x[a].blk_batch_stride};
-        // pageable source: the runtime stages the bytes before returning, so `desc` may die at the end of this call
-        HIPCHK(hipMemcpyAsync(e->dots_desc, desc.data(), (size_t)nx * sizeof(BlkRowDev), hipMemcpyHostToDevice, stream));
-        return PYRHE_OK;
+    auto table = [&](int a0, int n) {
+        BlkRowTable t;
+        for (int a = 0; a < kDescMax; ++a)
+            t.r[a] = a < n ? BlkRowDev{x[a0 + a].blk, x[a0 + a].mul, (long long)x[a0 + a].blk_batch_stride} : BlkRowDev{nullptr, nullptr, 0};
+        return t;
     };
     if (self && !no_fast) {
-        int rc = upload_desc();
-        if (rc) return rc;
+        const BlkRowTable tab = table(0, nx);
         const int zt = 16 / nx, tiles = (n_batch + zt - 1) / zt, tgs = (tiles + 3) / 4;
         int64_t n_chunks = std::max<int64_t>(1, 4096 / ((int64_t)tgs * n_sub));
         n_chunks = std::min<int64_t>(n_chunks, std::max<int64_t>(1, period / 256));
         const int chunk = (int)(((period + n_chunks - 1) / n_chunks + 31) / 32 * 32);
         n_chunks = (period + chunk - 1) / chunk;
         const int n_part = (int)n_chunks * n_sub;
-        rc = ensure_partial((size_t)tgs * n_part * 1024 * sizeof(double));
+        const int rc = ensure_partial((size_t)tgs * n_part * 1024 * sizeof(double));
         if (rc) return rc;
         dim3 grid((unsigned)((n_chunks + 3) / 4), n_sub, tgs);
-        blk_self_gram_kernel<<<grid, 256, 0, stream>>>(e->dots_desc, nx, n_batch, period, chunk, (int)n_chunks, e->dots_partial);
+        blk_self_gram_kernel<<<grid, 256, 0, stream>>>(tab, nx, n_batch, period, chunk, (int)n_chunks, e->dots_partial);
         blk_self_gram_reduce_kernel<<<(n_batch * nx * nx + 255) / 256, 256, 0, stream>>>(e->dots_partial, n_part, nx, n_batch, out);
         HIPCHK(hipGetLastError());
         return PYRHE_OK;
     }
     if (fast && !no_fast) {
-        {
-            const int rc = upload_desc();
+        for (int a0 = 0; a0 < nx; a0 += kDescMax) {
+            const int nxc = std::min(kDescMax, nx - a0);
+            const BlkRowTable tab = table(a0, nxc);
+            const int n_rows = nxc * n_batch;
+            const int rgs = (n_rows + 63) / 64;
+            int64_t n_chunks = std::max<int64_t>(1, 4096 / ((int64_t)rgs * n_sub));
+            n_chunks = std::min<int64_t>(n_chunks, std::max<int64_t>(1, period / 256));
+            const int chunk = (int)(((period + n_chunks - 1) / n_chunks + 31) / 32 * 32);
+            n_chunks = (period + chunk - 1) / chunk;
+            const int n_part = (int)n_chunks * n_sub;
+            const int rc = ensure_partial((size_t)rgs * n_part * 1024 * sizeof(double));
             if (rc) return rc;
-        }
-        const int n_rows = nx * n_batch;
-        const int rgs = (n_rows + 63) / 64;
-        int64_t n_chunks = std::max<int64_t>(1, 4096 / ((int64_t)rgs * n_sub));
-        n_chunks = std::min<int64_t>(n_chunks, std::max<int64_t>(1, period / 256));
-        const int chunk = (int)(((period + n_chunks - 1) / n_chunks + 31) / 32 * 32);
-        n_chunks = (period + chunk - 1) / chunk;
-        const int n_part = (int)n_chunks * n_sub;
-        const int rc = ensure_partial((size_t)rgs * n_part * 1024 * sizeof(double));
-        if (rc) return rc;
-        for (int b0 = 0; b0 < ny; b0 += 16) {
-            const int nyt = std::min(16, ny - b0);
-            FixedRows Y;
-            for (int c = 0; c < 16; ++c) Y.p[c] = c < nyt ? y[b0 + c].tot : nullptr;
-            dim3 grid((unsigned)((n_chunks + 3) / 4), n_sub, rgs);
-            blk_fixed_dots_kernel<<<grid, 256, 0, stream>>>(e->dots_desc, nx, n_rows, Y, nyt, period, chunk, (int)n_chunks, e->dots_partial);
-            blk_fixed_reduce_kernel<<<(n_rows * 16 + 255) / 256, 256, 0, stream>>>(e->dots_partial, n_part, n_rows, nyt, b0, ny, out);
+            for (int b0 = 0; b0 < ny; b0 += 16) {
+                const int nyt = std::min(16, ny - b0);
+                FixedRows Y;
+                for (int c = 0; c < 16; ++c) Y.p[c] = c < nyt ? y[b0 + c].tot : nullptr;
+                dim3 grid((unsigned)((n_chunks + 3) / 4), n_sub, rgs);
+                blk_fixed_dots_kernel<<<grid, 256, 0, stream>>>(tab, nxc, n_rows, Y, nyt, period, chunk, (int)n_chunks, e->dots_partial);
+                blk_fixed_reduce_kernel<<<(n_rows * 16 + 255) / 256, 256, 0, stream>>>(e->dots_partial, n_part, n_rows, nxc, a0, nx, nyt, b0, ny, out);
+            }
         }
         HIPCHK(hipGetLastError());
         return PYRHE_OK;

@@ -66,8 +66,11 @@ class BlockPlan:
         return cat, offs
 
     def block_counts(self, j: int) -> np.ndarray:
-        _, offs = self.entries(j)
-        return np.diff(offs)
+        """SNPs of block j in every bin (what partition_bins would select, base.py:315-336)."""
+        if not hasattr(self, "_counts"):
+            member = (self.annot != 0).astype(np.int64)
+            self._counts = np.stack([member[slice(*self.range(jj))].sum(axis=0) for jj in range(self.n_jack)])
+        return self._counts[j]
 
 
 # ----------------------------------------------------------------------------- imputation replay
@@ -597,22 +600,30 @@ class SketchRunner:
         return t + b, -b
 
     def _dots(self, x, y, n_sub, batch):
-        """loo_dots with None rows (exact zeros) filtered out; float64 numpy [batch, len(x), len(y)]."""
+        """loo_dots with None rows (exact zeros) filtered out; float64 DEVICE tensor [batch, len(x), len(y)] -- nothing
+        here waits for the GPU (a blocking copy per call costs more than the kernels)."""
         xi = [i for i, r in enumerate(x) if r is not None]
         yi = [i for i, r in enumerate(y) if r is not None]
-        out = np.zeros((batch, len(x), len(y)))
-        if xi and yi:
-            res = self.eng.loo_dots([x[i] for i in xi], [y[i] for i in yi], self.n_pad, n_sub, batch)
-            out[np.ix_(range(batch), xi, yi)] = res.cpu().numpy()
+        if not xi or not yi:
+            return torch.zeros((batch, len(x), len(y)), dtype=torch.float64, device=self.device)
+        res = self.eng.loo_dots([x[i] for i in xi], [y[i] for i in yi], self.n_pad, n_sub, batch)
+        if len(xi) == len(x) and len(yi) == len(y):
+            return res
+        out = torch.zeros((batch, len(x), len(y)), dtype=torch.float64, device=self.device)
+        ix = torch.as_tensor(xi, device=self.device)
+        iy = torch.as_tensor(yi, device=self.device)
+        out[:, ix[:, None], iy[None, :]] = res
         return out
 
     def _loo_systems(self, tots, nxe, store, batch, M_rows, yy):
         """Normal equations (base.py:568-628) of ``batch`` slots: whole-data accumulators minus the stored sketches of
-        ``batch`` blocks (``store`` None: the whole-data slot).  Returns T ``[batch, ne+1, ne+1]``, q ``[batch, ne+1]``."""
+        ``batch`` blocks (``store`` None: the whole-data slot).  Returns T ``[batch, ne+1, ne+1]``, q ``[batch, ne+1]``
+        (NumPy); the inner products and the small algebra stay on the device, one copy brings T and q back."""
         from .engine import Row
         tot_A, tot_C, D_tot, tot_r = tots
         ne, k, nb = self.n_est, self.k, self.plan.n_bin
         use_cov = self.cov is not None
+        dev, f64 = self.device, torch.float64
         nA = nC = nD = None
         if self.n_nxe:
             nA = nxe[0][0]
@@ -632,7 +643,7 @@ class SketchRunner:
             fixed.append(Row(self.UZ64))
         bpart = self._dots(A_blk, fixed, k, batch)                # block rows evaluate to -blk: -<b_a, fixed>
         g = self._dots(A_tot, fixed, k, 1) + bpart
-        gram = g[:, :, :ne] + np.transpose(bpart[:, :, :ne], (0, 2, 1)) + self._dots(A_blk, A_blk, k, batch)
+        gram = g[:, :, :ne] + bpart[:, :, :ne].transpose(1, 2) + self._dots(A_blk, A_blk, k, batch)
         col = ne
         tz = tk = None
         if self.genie_model is not None:
@@ -649,12 +660,13 @@ class SketchRunner:
             # UXXz_b = whole-data UXXz_b - U(block XXz_b), streaming_rhe.py:35-36)
             PA, PbA = (t.reshape(batch, ne, k, c) for t in self._lin_dots(self._sub_rows(A), Wr, 1, batch))
             PC = self._lin_dots(self._sub_rows(Cr), Wr, 1, batch)[0].reshape(batch, ne, k, c)
-            Q = self.Q
-            uaa = np.einsum("zasm,mn,zbsn->zab", PA, Q, PA)
-            cd = gCD - np.einsum("zasm,mn,zbsn->zab", PC, Q, PbA)
+            Q = self.Q64
+            flat = lambda P: P.reshape(batch, ne, k * c)
+            uaa = flat(PA @ Q) @ flat(PA).transpose(1, 2)
+            cd = gCD - flat(PC @ Q) @ flat(PbA).transpose(1, 2)
             gram = gram + cd - 2.0 * uaa
         # r = yXXy: whole-data minus block
-        r = tot_r.cpu().numpy()[None, :].repeat(batch, axis=0)
+        r = tot_r[None, :].expand(batch, -1)
         if store is not None:
             py, cy = self.loc["y"]
             parts = [store[1][py][:batch, :, cy]]
@@ -663,26 +675,28 @@ class SketchRunner:
             if self.n_gxe:
                 pe, ce = self.loc["ey"]
                 parts.append(store[1][pe][:batch, :, ce])
-            r = r - torch.cat(parts, dim=1).cpu().numpy()
+            r = r - torch.cat(parts, dim=1)
         if self.n_nxe:
-            r = np.concatenate([r, np.broadcast_to(nxe[2].cpu().numpy()[None, :], (batch, 1))], axis=1)
-        Mf = M_rows.astype(np.float64)                            # [batch, ne]
-        T = np.zeros((batch, ne + 1, ne + 1))
-        q = np.zeros((batch, ne + 1))
+            r = torch.cat([r, nxe[2][None, :].expand(batch, 1)], dim=1)
+        Mf = torch.as_tensor(M_rows.astype(np.float64), device=dev)     # [batch, ne]
+        T = torch.zeros((batch, ne + 1, ne + 1), dtype=f64, device=dev)
+        q = torch.zeros((batch, ne + 1), dtype=f64, device=dev)
         mm = Mf[:, :, None] * Mf[:, None, :]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            T[:, :ne, :ne] = np.where(mm != 0, gram / k / mm, 0.0)
-            tr = np.full((batch, ne), float(self.N))              # rhe.py:24-26
-            if self.genie_model is not None and ne > nb:
-                tr[:, nb:] = tz[:, nb:] / (k * Mf[:, nb:])         # stochastic trace of a GxE / NxE kernel (genie.py:85-89)
-            if use_cov:
-                tr = tr - tk / (k * Mf)                            # base.py:614-615
-            q[:, :ne] = np.where(Mf != 0, r / Mf, 0.0)
+        zero = torch.zeros((), dtype=f64, device=dev)
+        T[:, :ne, :ne] = torch.where(mm != 0, gram / k / mm, zero)
+        tr = torch.full((batch, ne), float(self.N), dtype=f64, device=dev)       # rhe.py:24-26
+        if self.genie_model is not None and ne > nb:
+            tr[:, nb:] = tz[:, nb:] / (k * Mf[:, nb:])             # stochastic trace of a GxE / NxE kernel (genie.py:85-89)
+        if use_cov:
+            tr = tr - tk / (k * Mf)                                # base.py:614-615
+        q[:, :ne] = torch.where(Mf != 0, r / Mf, zero)
         T[:, :ne, ne] = tr
         T[:, ne, :ne] = tr
         T[:, ne, ne] = self.N - (self.cov.shape[1] if use_cov else 0)
         q[:, ne] = yy
-        return T, q
+        both = torch.cat([T.reshape(batch, -1), q], dim=1).cpu().numpy()         # the one blocking copy
+        n2 = (ne + 1) * (ne + 1)
+        return both[:, :n2].reshape(batch, ne + 1, ne + 1).copy(), both[:, n2:].copy()
 
     def _stored_block(self, jl_i: int):
         sk, nm = [b[jl_i] for b in self.blocks_sk], [b[jl_i] for b in self.blocks_nm]

@@ -22,25 +22,36 @@ runner = SketchRunner(engine, geno, plan, (0, jn), n_orig=N, missing_indv=[], Z=
 runner.begin_trait(y, check_missing=False)
 runner.pass1(); torch.cuda.synchronize()
 t0 = time.perf_counter(); runner.pass1(); torch.cuda.synchronize(); print("pass1 s", time.perf_counter() - t0)
+t0 = time.perf_counter(); runner.pass2(); torch.cuda.synchronize(); print("pass2 (first call) s", time.perf_counter() - t0)
 pr = cProfile.Profile(); pr.enable()
 t0 = time.perf_counter(); runner.pass2(); torch.cuda.synchronize(); print("pass2 s", time.perf_counter() - t0)
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
 
 if os.environ.get("TRACE_DOTS"):
+    sync = os.environ["TRACE_DOTS"] == "1"
     orig = runner._dots
     def traced(x, y, n_sub, batch):
-        torch.cuda.synchronize(); t = time.perf_counter()
-        ld = runner.eng.loo_dots
-        def ld2(*a, **k):
-            t1 = time.perf_counter(); r = ld(*a, **k); t2 = time.perf_counter(); torch.cuda.synchronize(); t3 = time.perf_counter()
-            print(f"    loo_dots enqueue {(t2-t1)*1e3:.2f} ms, gpu wait {(t3-t2)*1e3:.2f} ms")
-            return r
-        runner.eng.loo_dots = ld2
+        if sync: torch.cuda.synchronize()
+        t = time.perf_counter()
         out = orig(x, y, n_sub, batch)
-        runner.eng.loo_dots = ld
-        torch.cuda.synchronize()
         print(f"_dots nx={len(x)} ny={len(y)} n_sub={n_sub} batch={batch} blkx={sum(r is not None and r.blk is not None for r in x)} totx={sum(r is not None and r.tot is not None for r in x)}: {(time.perf_counter()-t)*1e3:.2f} ms")
         return out
     runner._dots = traced
-    t0 = time.perf_counter(); runner.pass2(); torch.cuda.synchronize(); print("pass2 traced s", time.perf_counter() - t0)
+    import pyrhe_amd.engine as E
+    lib = runner.eng.lib
+    raw = lib.pyrhe_engine_loo_dots
+    class W:
+        def __call__(self, *a):
+            t = time.perf_counter(); r = raw(*a); dt = (time.perf_counter() - t) * 1e3
+            if dt > 2: print(f"   C call pyrhe_engine_loo_dots took {dt:.2f} ms")
+            return r
+    lib.pyrhe_engine_loo_dots = W()
+    _cpu = torch.Tensor.cpu
+    def cpu2(self, *a, **k):
+        t = time.perf_counter(); r = _cpu(self, *a, **k); dt = (time.perf_counter() - t) * 1e3
+        if dt > 8: print(f"   .cpu() took {dt:.2f} ms shape {tuple(self.shape)}")
+        return r
+    torch.Tensor.cpu = cpu2
+    for rep in range(2):
+        t0 = time.perf_counter(); runner.pass2(); torch.cuda.synchronize(); print("pass2 traced s", time.perf_counter() - t0)
