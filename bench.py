@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--n-bin", type=int, default=1, help="annotation bins (bin(s) = hash(s) mod n_bin; BASELINE configs[3] uses 8)")
     ap.add_argument("--n-cov", type=int, default=0, help="covariate columns incl. intercept (configs[3]: 11)")
+    ap.add_argument("--genie", default=None, choices=["G+GxE", "G+GxE+NxE"],
+                    help="StreamingGENIE sketch pass with one Bernoulli(0.5) environment (BASELINE configs[4])")
     ap.add_argument("--precision", default=os.environ.get("PYRHE_PRECISION", "i8x3"), choices=["f16", "f16x2", "f16e", "i8x3"])
     ap.add_argument("--sub-snps", type=int, default=int(os.environ.get("PYRHE_SUB_SNPS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,8 +132,17 @@ def main():
     cov = None
     if args.n_cov > 0:
         cov = np.concatenate([np.ones((N, 1)), np.random.default_rng(2).normal(size=(N, args.n_cov - 1))], axis=1)
-    runner = SketchRunner(engine, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True,
-                          compat="fixed" if cov is not None else "reference")
+    env = None
+    engines = engine
+    if args.genie:
+        env = np.random.default_rng(3).integers(0, 2, size=N).astype(np.float64)     # Bernoulli(0.5)
+        n_cols = (2 if cov is None else 4) * k + 2
+        if n_cols > 30:                               # [Z, UZ | y] and [e.Z, e.UZ | e.y] on two engines
+            engines = [engine, eng_mod.SketchEngine(N, N, max_entries=plan.max_block, precision=args.precision, device=dev,
+                                                    sub_snps=args.sub_snps)]
+    runner = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, cov=cov, env=env,
+                          genie_model=args.genie, seed=0, streaming=True,
+                          compat="fixed" if (cov is not None or args.genie) else "reference")
     runner.begin_trait(y, check_missing=False)      # the generator emits no missing calls (contract of synth_kernel)
 
     def barrier():
@@ -188,8 +199,9 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": {"f16x2": "f16x2", "i8x3": "i8x3+f16x2", "f16": "f16", "f16e": "f16"}[args.precision], "data": "synthetic",
-           "config": {"workload": f"synthetic N={N} M={M} {args.n_bin}-bin StreamingRHE sketch pass, k={k} jn={jn}"
-                                  + (f", {args.n_cov} covariates" if args.n_cov else ""),
+           "config": {"workload": f"synthetic N={N} M={M} {args.n_bin}-bin "
+                                  + (f"StreamingGENIE {args.genie} (1 environment)" if args.genie else "StreamingRHE")
+                                  + f" sketch pass, k={k} jn={jn}" + (f", {args.n_cov} covariates" if args.n_cov else ""),
                       "precision": args.precision, "sub_snps": engine.sub_snps, "parallelism": f"blocks/{world}gpu",
                       "gen_seconds": round(t_gen, 2)},
            "roofline": roofline}

@@ -89,3 +89,53 @@ def test_linearity_and_block_additivity_at_bench_sample_count():
     assert torch.equal(cs, s) and int(nmiss.sum()) == 0
     assert not full[:, :, n:].any()                       # padding samples stay exactly zero
     eng.close()
+
+
+@pytest.mark.parametrize("case", ["rhe_cov", "genie_nxe_cov", "dom_cov", "rhe_cov_q4", "rhe_recompute"])
+def test_pass2_device_assembly_equals_materialised_torch_path(case):
+    """The normal equations assembled from pyrhe_engine_loo_dots (batched, expanded around the whole-data rows,
+    covariate projector applied through projections) equal the ones from materialised leave-one-out arrays and torch
+    float64 reductions -- every model family, covariates, both UXXz semantics, stored and re-sketched blocks."""
+    from pyrhe_amd import engine
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner
+    dev = torch.device("cuda", 0)
+    n, m, jn, k, nbin = 6000, 1200, 8, 10, 3
+    geno = engine.synth_genotypes(m, n, SEED, 11, dev)
+    rng = np.random.default_rng(9)
+    annot = np.zeros((m, nbin), np.int64)
+    annot[np.arange(m), rng.integers(0, nbin, m)] = 1
+    annot[rng.choice(m, 100, replace=False), 0] = 1                 # some SNPs in two bins
+    plan = BlockPlan(annot, jn)
+    np.random.seed(0)
+    Z = np.random.randn(n, k)
+    y = rng.normal(size=n); y -= y.mean()
+    cov = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, 3))], axis=1)
+    env = rng.integers(0, 2, n).astype(np.float64)
+    kw = dict(n_orig=n, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True, compat="fixed")
+    n_eng = 1
+    if case == "genie_nxe_cov":
+        kw.update(env=env, genie_model="G+GxE+NxE")
+        n_eng = 2                                                    # 4 k + 2 columns
+    elif case == "dom_cov":
+        kw.update(dom=True)
+    elif case == "rhe_cov_q4":
+        kw.update(compat="reference")
+    elif case == "rhe_recompute":
+        kw.update(recompute_pass2=True)
+    engs = [engine.SketchEngine(n, n, plan.max_block, device=dev) for _ in range(n_eng)]
+    runner = SketchRunner(engs if n_eng > 1 else engs[0], geno, plan, (0, jn), **kw)
+    runner.begin_trait(y, check_missing=False)
+    runner.pass1()
+    a = runner.pass2()
+    runner.pass2_impl = "torch"
+    b = runner.pass2()
+    assert np.array_equal(a.M, b.M)
+    # U(block XXz) is float32 in the materialised path (streaming_rhe.py:35-36) and float64 through the projections
+    tol = 2e-6
+    assert np.abs(a.T - b.T).max() <= tol * np.abs(b.T).max(), np.abs(a.T - b.T).max() / np.abs(b.T).max()
+    assert np.allclose(a.q, b.q, rtol=1e-12, atol=0)
+    for j in range(jn + 1):
+        sa = np.linalg.solve(a.T[j], a.q[j]); sb = np.linalg.solve(b.T[j], b.q[j])
+        assert np.abs(sa - sb).max() <= 1e-5 * np.abs(sb).max()
+    for e_ in engs:
+        e_.close()
