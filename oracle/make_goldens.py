@@ -83,6 +83,9 @@ CASES = [
          kw=dict(num_jack=10, num_random_vec=10, seed=2)),
     dict(name="srhe_3bin_cov", cohort=dict(n_indv=403, n_snp=247, seed=13, nbin=3, overlap=True, with_cov=3),
          model="StreamingRHE", kw=dict(num_jack=10, num_random_vec=10, seed=2)),
+    # (StreamingRHE without covariates raises AttributeError in the reference's aggregate, base_streaming.py:29)
+    dict(name="srhe_2bin_missing_cov", cohort=dict(n_indv=403, n_snp=240, seed=25, nbin=2, missing_geno=0.02, missing_pheno=5, with_cov=3),
+         model="StreamingRHE", kw=dict(num_jack=10, num_random_vec=10, seed=3)),
     dict(name="rhe_1bin_missing", cohort=dict(n_indv=403, n_snp=240, seed=14, missing_geno=0.02, missing_pheno=5),
          model="RHE", kw=dict(num_jack=10, num_random_vec=10, seed=3)),
     dict(name="rhe_1bin_missing_mean", cohort=dict(n_indv=403, n_snp=240, seed=14, missing_geno=0.02, missing_pheno=5),

@@ -296,7 +296,12 @@ def precompute(p: Problem, streaming_compat: bool = False) -> State:
     if p.Z is None:
         p.Z = make_probe_vectors(p.seed, p.n_indv, p.k)
     if streaming_compat:
-        np.random.seed(p.seed)   # stream continues from construction in the reference; caller handles exact replay
+        # The one-worker multiprocessing mode forks its pass-1 worker from the parent right after construction, so the
+        # worker's legacy stream stands where Base.__init__ left it: seed (base.py:73), then randn(N, k) (base.py:176).
+        # The pass-2 worker is forked from the SAME parent state (mp_handler.py:28-37), so it re-imputes every block
+        # with the same draws: both passes see identical genotypes, which is what reusing `blocks` below expresses.
+        np.random.seed(p.seed)
+        np.random.randn(p.n_indv, p.k)
     jn, ne, k, N = p.n_jack, p.n_est, p.k, p.n_indv
     blocks = [sketch_block(p, j, reseed=not streaming_compat) for j in range(jn)]
     st = State(np.zeros((ne, jn + 1, k, N)), np.zeros((ne, jn + 1)), np.zeros((jn + 1, ne), np.int64), blocks=blocks)

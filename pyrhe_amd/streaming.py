@@ -264,7 +264,9 @@ class SketchRunner:
 
     def _uniform_stream(self, pass_index: int):
         """Replay NumPy's legacy stream the way the reference consumes it (base.py:73,176,266,510;
-        base_streaming.py:85-104,110-118): non-streaming reseeds per block, streaming keeps drawing."""
+        base_streaming.py:85-104,110-118): non-streaming reseeds per block, streaming keeps drawing.  ``pass_index`` 1
+        is the in-process (multiprocessing=False) pass 2, whose stream continues behind pass 1; the one-worker
+        multiprocessing mode this package mirrors forks both workers from the same state (pass_index 0 twice)."""
         if self.impute != "binary":
             return lambda j, m: None
         if not self.streaming:
@@ -705,11 +707,25 @@ class SketchRunner:
         return sk, nm, None, None
 
     def _resketch(self, j: int):
+        """Sketch block j again (the reference's pass 2 re-reads and re-imputes, base_streaming.py:110-118).  Blocks are
+        visited in ascending order; missing calls get the SAME fill values as in pass 1: the reference's pass-2 worker
+        is forked from the same parent state as its pass-1 worker (mp_handler.py:28-37), so it replays the same draws."""
         ent, offs = self._entries(j)
+        fill = None
+        if self._check_missing and self._ingest_stats()[1].any():
+            if getattr(self, "_redraw", None) is None or self._redraw[0] > j:
+                self._redraw = [self.j0, self._uniform_stream(0)]
+            s, e = self.plan.range(j)
+            while self._redraw[0] < j:                    # blocks skipped since the last call still consume draws
+                s2, e2 = self.plan.range(self._redraw[0])
+                self._redraw[1](self._redraw[0], e2 - s2)
+                self._redraw[0] += 1
+            fill = self._fill_for_block(j, self._redraw[1](j, e - s))
+            self._redraw[0] = j + 1
         if self.dom:
-            outs = [self.engs[p].sketch_block_dom(self._block_rows(j), ent, offs) for p in range(self.n_pass)]
+            outs = [self.engs[p].sketch_block_dom(self._block_rows(j), ent, offs, fill=fill) for p in range(self.n_pass)]
             return [o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], [o[3] for o in outs]
-        outs = [self.engs[p].sketch_block(self._block_rows(j), ent, offs) for p in range(self.n_pass)]
+        outs = [self.engs[p].sketch_block(self._block_rows(j), ent, offs, fill=fill) for p in range(self.n_pass)]
         return [o[0] for o in outs], [o[1] for o in outs], None, None
 
     def _allreduce(self, t: torch.Tensor):

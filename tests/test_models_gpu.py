@@ -71,6 +71,17 @@ def test_streaming_rhe_bug_compatible_and_fixed(tmp_path):
     _assert_dict(m2(trait=0), zf, 0, RESULT_KEYS_RHE)
 
 
+def test_streaming_rhe_missing_calls_with_covariates(tmp_path):
+    """StreamingRHE + covariates + missing genotype calls / dropped individuals: the reference's one-worker mode
+    (imputation draws continue behind the probe-vector draws; both passes see the same imputed genotypes)."""
+    z = load_golden("srhe_2bin_missing_cov")
+    m, _ = _run_model(z, tmp_path, "StreamingRHE")
+    _assert_dict(m(trait=0), z, 0, RESULT_KEYS_RHE)
+    assert np.allclose(m.sigma_est_jackknife, z["ref_t0_sigma_jack"], rtol=RTOL)
+    m2, _ = _run_model(z, tmp_path, "StreamingRHE", recompute_pass2=True)
+    _assert_dict(m2(trait=0), z, 0, RESULT_KEYS_RHE)
+
+
 def test_recompute_pass2_equals_stored_blocks(tmp_path):
     z = load_golden("rhe_3bin_nocov_rem")
     a, _ = _run_model(z, tmp_path, "StreamingRHE")

@@ -53,6 +53,8 @@ def test_rhe_streaming_bug_compatible(name):
     assert close(r["sigma_jack"], z["ref_t0_sigma_jack"])
     for k in RESULT_KEYS_RHE:
         assert close(r[k], z["ref_t0_res_" + k]), k
+    if name != "srhe_3bin_cov":
+        return
     # and it differs from the non-streaming ("fixed") semantics by the documented ~1 % (quirk Q4)
     zf = load_golden("rhe_3bin_cov")
     rel = np.abs(r["sigma_ests_total"] - zf["ref_t0_res_sigma_ests_total"]) / np.abs(zf["ref_t0_res_sigma_ests_total"])
