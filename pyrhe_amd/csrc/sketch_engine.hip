@@ -411,7 +411,7 @@ __global__ void prep_rimg_i8_kernel(const float* __restrict__ R, const float* __
 }
 
 template <int NTL, bool MISSING, int GV = 0>
-__global__ __launch_bounds__(256) void gemm1_i8_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
+__global__ __launch_bounds__(256, NTL == 1 ? 3 : 1) void gemm1_i8_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                        const int32_t* __restrict__ rows, int n_entries,
                                                        const float* __restrict__ fill,
                                                        const int4v* __restrict__ rimg, int n_steps,
@@ -445,7 +445,6 @@ __global__ __launch_bounds__(256) void gemm1_i8_kernel(const uint8_t* __restrict
 #pragma unroll
             for (int n = 0; n < NTL; ++n) acc[t][l][n] = (int4v){0, 0, 0, 0};
     uint4 g[2][4][CH];
-    int4v rs[LD];
     auto issue_g = [&](int s, uint4 (&gg)[4][CH]) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -453,28 +452,27 @@ __global__ __launch_bounds__(256) void gemm1_i8_kernel(const uint8_t* __restrict
             for (int ch = 0; ch < CH; ++ch)
                 gg[t][ch] = *reinterpret_cast<const uint4*>(rowp[t] + (int64_t)s * (64 * CH) + 64 * ch);
     };
-    auto issue_r = [&](int s) {
+    // R image of a step -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write): the image is
+    // stored in fragment order, so every wave-instruction copies one contiguous 1-KiB fragment (lane-linear in LDS).
+    auto issue_r = [&](int s, int buf) {
         const int4v* src = rimg + (int64_t)s * (CH * FR * 64) + threadIdx.x;
+        int4v* dst = ibuf + buf * (CH * FR * 64) + wave * 64;            // wave-uniform base; lane l lands at +l
 #pragma unroll
-        for (int i = 0; i < LD; ++i) rs[i] = src[i * 256];
-    };
-    auto stage_r = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < LD; ++i) ibuf[buf * (CH * FR * 64) + i * 256 + threadIdx.x] = rs[i];
+        for (int i = 0; i < LD; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
     };
     auto compute = [&](const uint4 (&gg)[4][CH], int buf) {
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
             const int4v* rf = ibuf + buf * (CH * FR * 64) + ch * (FR * 64) + lane;
-            int4v b[4][3][NTL];
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
+            for (int d = 0; d < 4; ++d) {
+                int4v b[3][NTL];
 #pragma unroll
                 for (int l = 0; l < 3; ++l)
 #pragma unroll
-                    for (int n = 0; n < NTL; ++n) b[d][l][n] = rf[((d * 3 + l) * NTL + n) * 64];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
+                    for (int n = 0; n < NTL; ++n) b[l][n] = rf[((d * 3 + l) * NTL + n) * 64];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const uint32_t w = d == 0 ? gg[t][ch].x : (d == 1 ? gg[t][ch].y : (d == 2 ? gg[t][ch].z : gg[t][ch].w));
@@ -486,26 +484,39 @@ __global__ __launch_bounds__(256) void gemm1_i8_kernel(const uint8_t* __restrict
                     for (int l = 0; l < 3; ++l)
 #pragma unroll
                         for (int n = 0; n < NTL; ++n)
-                            acc[t][l][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[d][l][n], acc[t][l][n], 0, 0, 0);
+                            acc[t][l][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[l][n], acc[t][l][n], 0, 0, 0);
                 }
             }
         }
     };
+    // Touch every register of a packed-word stage: the compiler's wait for those loads lands HERE, before this step's
+    // new loads are issued (with an LDS-DMA in flight hipcc waits vmcnt(0) at the first use of an ordinary load).
+    auto touch = [&](const uint4 (&gg)[4][CH]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch)
+                asm volatile("" ::"v"(gg[t][ch].x), "v"(gg[t][ch].y), "v"(gg[t][ch].z), "v"(gg[t][ch].w));
+    };
+    issue_r(s0, 0);
     issue_g(s0, g[0]);
-    issue_r(s0);
-    stage_r(0);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     for (int s = s0; s < s1; s += 2) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int nxt = min(s + k + 1, s1 - 1);
-            issue_r(nxt);
+            touch(g[k]);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_r(nxt, k ^ 1);
             issue_g(nxt, g[k ^ 1]);
             __builtin_amdgcn_sched_barrier(0);
             compute(g[k], k);
             __builtin_amdgcn_sched_barrier(0);
-            stage_r(k ^ 1);
-            __syncthreads();
+            // the LD LDS-DMAs are older than the 4*CH packed-word loads behind them: leave those in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * CH) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
     }
     // P layout: [entry][limb][16 NTL columns] int32
