@@ -411,12 +411,15 @@ __global__ void prep_rimg_i8_kernel(const float* __restrict__ R, const float* __
 }
 
 template <int NTL, bool MISSING, int GV = 0>
-__global__ __launch_bounds__(256, NTL == 1 ? 3 : 1) void gemm1_i8_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
+__global__ __launch_bounds__(256, NTL == 1 ? 3 : 2) void gemm1_i8_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                        const int32_t* __restrict__ rows, int n_entries,
                                                        const float* __restrict__ fill,
                                                        const int4v* __restrict__ rimg, int n_steps,
                                                        int steps_per_split, int* __restrict__ P, int use_atomic) {
-    constexpr int CH = 2;                        // 256-sample chunks per step
+    // 256-sample chunks per step.  One column tile: 512-sample steps (a full 128-B line per row) at 154 registers = 3
+    // waves per SIMD.  Two tiles: 256-sample steps keep the kernel at 178 registers = 2 waves per SIMD (with 512-sample
+    // steps it needs 322 and runs one wave per SIMD: 56 -> 41 ms per pass on the 8-bin + covariates configuration).
+    constexpr int CH = NTL == 1 ? 2 : 1;
     constexpr int FR = 12 * NTL;                 // 1-KiB fragments per chunk: 4 dwords x 3 limbs x NTL
     constexpr int LD = CH * FR / 4;
     extern __shared__ __attribute__((aligned(16))) int4v ibuf[];   // [2][CH * FR * 64]
@@ -1946,7 +1949,8 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     // ---- GEMM 1 of one entry list, genotype view gv, into Pbuf (zeroed by the caller)
     auto run_gemm1 = [&](int gv, const int32_t* rows, int n, float* Pbuf) {
         const int gx = (n + 255) / 256;
-        const int n_steps = n_chunks / 2;                 // 512-sample steps (pitch is a multiple of 256 B)
+        const int g1_ch = (e->i8 && e->ntl > 1) ? 1 : 2;  // 256-sample chunks per step (see gemm1_i8_kernel)
+        const int n_steps = n_chunks / g1_ch;             // pitch is a multiple of 256 B = 4 chunks
         static const int g1_wgs = getenv("PYRHE_G1_WGS") ? atoi(getenv("PYRHE_G1_WGS")) : 1536;   // target workgroups per launch
         int splits = (g1_wgs + gx - 1) / gx;
         splits = std::max(1, std::min(splits, n_steps / 4 > 0 ? n_steps / 4 : 1));
@@ -1959,7 +1963,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         dim3 grid(gx, splits);
         const int ua = splits > 1;
         if (e->i8) {
-            const size_t lds = (size_t)2 * 2 * 12 * e->ntl * 1024;
+            const size_t lds = (size_t)2 * g1_ch * 12 * e->ntl * 1024;
 #define G1I(NTL_, MISS_, GV_) gemm1_i8_kernel<NTL_, MISS_, GV_><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua)
             if (gv == 0) { if (e->ntl == 1) { if (fill) G1I(1, true, 0); else G1I(1, false, 0); } else { if (fill) G1I(2, true, 0); else G1I(2, false, 0); } }
             else         { if (e->ntl == 1) { if (fill) G1I(1, true, 1); else G1I(1, false, 1); } else { if (fill) G1I(2, true, 1); else G1I(2, false, 1); } }
