@@ -208,20 +208,20 @@ def main():
 
     if True:     # pass 2 + solves are cheap next to the sketch pass: always timed, reported beside the metric
         w = runner.pass2()                                                  # untimed: scratch allocation, BLAS thread start
-        est.solve_normal_equations(w.T[0], w.q[0].reshape(-1, 1))
+        est.solve_all(w.T[:1], w.q[:1])
         barrier()
         t0 = time.perf_counter()
         sysm = runner.pass2()
         barrier()
         t_pass2 = time.perf_counter() - t0
-        sig = [est.solve_normal_equations(sysm.T[j], sysm.q[j].reshape(-1, 1)) for j in range(jn + 1)]
+        sig = est.solve_all(sysm.T, sysm.q)
         t_solve = time.perf_counter() - t0 - t_pass2
         # end to end = one sketch pass (incl. aggregate + all-reduce) + pass 2 (LOO systems) + the jn+1 solves
         out["config"]["end_to_end"] = {"pass1_s": round(ms_per_step / 1e3, 4), "pass2_s": round(t_pass2, 4), "solve_s": round(t_solve, 4),
                                        "snps_per_s": M / (ms_per_step / 1e3 + t_pass2 + t_solve)}
         if args.verify:
             out["config"]["sigma_total"] = [float(v) for v in sig[-1]]
-            out["config"]["sigma_se"] = [float(v) for v in est.jackknife_se(np.array(sig[:-1]), jn)]
+            out["config"]["sigma_se"] = [float(v) for v in est.jackknife_se(sig[:-1], jn)]
 
     if not args.no_alt and args.precision in ("f16x2", "i8x3"):
         # the same pass in the single-rounding mode (1 MFMA per fragment, subnormal unpack): reported beside the

@@ -17,6 +17,20 @@ def solve_normal_equations(T: np.ndarray, q: np.ndarray, method: str = "QR") -> 
     raise ValueError("Unsupported method for solving linear equation")
 
 
+def solve_all(T: np.ndarray, q: np.ndarray, method: str = "QR") -> np.ndarray:
+    """The jn+1 solves of one trait, ``T [jn+1, ne+1, ne+1]``, ``q [jn+1, ne+1]`` -> ``[jn+1, ne+1]``.  The systems are
+    (ne+1) x (ne+1): the BLAS/LAPACK thread pool is pinned to one thread for the loop (on a 256-core host waking the
+    pool costs tens of milliseconds, the solves themselves microseconds)."""
+    def run():
+        return np.array([solve_normal_equations(T[j], np.asarray(q[j]).reshape(-1, 1), method) for j in range(T.shape[0])])
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        return run()
+    with threadpool_limits(limits=1):
+        return run()
+
+
 def jackknife_se(ests: np.ndarray, n_jack: int) -> list:
     """Delete-one-block jackknife SE per column: sqrt((jn-1)/jn * sum_j (theta_j - mean)^2)  (base.py:680-703)."""
     ests = np.asarray(ests)

@@ -148,9 +148,7 @@ class Base:
         self.log._debug(f"Precompute total time: {time.time() - t0}")
 
     def estimate(self, method: str = "lstsq"):
-        rows = [est.solve_normal_equations(self.systems.T[j], self.systems.q[j].reshape(-1, 1), method)
-                for j in range(self.num_jack + 1)]
-        rows = np.array(rows)
+        rows = est.solve_all(self.systems.T[:self.num_jack + 1], self.systems.q[:self.num_jack + 1], method)
         if self.get_trace and self.rank == 0:
             self.get_trace_summary()
         return rows[:-1, :], rows[-1, :]
@@ -359,13 +357,9 @@ class GENIE(Base):
     def estimate(self, method: str = "lstsq"):
         """Variance components and their trace-adjusted copies sigma_i * T[i, ne] (genie.py:97-144)."""
         ne = self.num_estimates
-        rows, adj = [], []
-        for j in range(self.num_jack + 1):
-            T = self.systems.T[j]
-            s = est.solve_normal_equations(T, self.systems.q[j].reshape(-1, 1), method)
-            rows.append(s)
-            adj.append([s[i] * T[i, ne] for i in range(len(s))])
-        rows, adj = np.array(rows), np.array(adj)
+        T = self.systems.T[:self.num_jack + 1]
+        rows = est.solve_all(T, self.systems.q[:self.num_jack + 1], method)
+        adj = rows * T[:, :rows.shape[1], ne]
         return rows[:-1, :], rows[-1, :], adj[:-1, :], adj[-1, :]
 
     def run(self, method):
