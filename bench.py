@@ -108,10 +108,14 @@ def main():
     r1 = plan.range(j1 - 1)[1] if j1 > j0 else 0
     t_gen = time.perf_counter()
     geno = eng_mod.synth_genotypes(r1 - r0, N, SYNTH_SEED, r0, dev)          # resident in HBM before timing
+    coding = os.environ.get("PYRHE_CODING", "value")
+    if coding == "value":
+        eng_mod.recode_rows(geno, "value")       # the load-time recode of the product path (models.py), outside the timing
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     engine = eng_mod.SketchEngine(N, N, max_entries=plan.max_block, precision=args.precision, device=dev,
                                   sub_snps=args.sub_snps)
+    engine.set_coding(coding)
     np.random.seed(0)
     Z = np.random.randn(N, k)                                               # NumPy legacy stream, seed 0
     y = np.random.default_rng(1).normal(size=N); y -= y.mean()
@@ -120,6 +124,7 @@ def main():
         r = np.random.default_rng(7).normal(size=(N, 1))
         # always built in the parity-safe mode, so that every --precision is verified on the SAME phenotype
         eng_y = eng_mod.SketchEngine(N, N, max_entries=plan.max_block, precision="i8x3", device=dev, sub_snps=args.sub_snps)
+        eng_y.set_coding(coding)
         rr = SketchRunner(eng_y, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=r, seed=0, streaming=True)
         rr.begin_trait(y, check_missing=False)
         rr.pass1()
@@ -140,6 +145,7 @@ def main():
         if n_cols > 30:                               # [Z, UZ | y] and [e.Z, e.UZ | e.y] on two engines
             engines = [engine, eng_mod.SketchEngine(N, N, max_entries=plan.max_block, precision=args.precision, device=dev,
                                                     sub_snps=args.sub_snps)]
+            engines[1].set_coding(coding)
     runner = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, cov=cov, env=env,
                           genie_model=args.genie, seed=0, streaming=True,
                           compat="fixed" if (cov is not None or args.genie) else "reference")
@@ -202,7 +208,7 @@ def main():
            "config": {"workload": f"synthetic N={N} M={M} {args.n_bin}-bin "
                                   + (f"StreamingGENIE {args.genie} (1 environment)" if args.genie else "StreamingRHE")
                                   + f" sketch pass, k={k} jn={jn}" + (f", {args.n_cov} covariates" if args.n_cov else ""),
-                      "precision": args.precision, "sub_snps": engine.sub_snps, "parallelism": f"blocks/{world}gpu",
+                      "precision": args.precision, "coding": coding, "sub_snps": engine.sub_snps, "parallelism": f"blocks/{world}gpu",
                       "gen_seconds": round(t_gen, 2)},
            "roofline": roofline}
 
@@ -229,6 +235,7 @@ def main():
         del runner
         engine.close()
         engine = eng_mod.SketchEngine(N, N, max_entries=plan.max_block, precision="f16", device=dev, sub_snps=args.sub_snps)
+        engine.set_coding(coding)
         runner = SketchRunner(engine, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True,
                               compat="fixed" if cov is not None else "reference")
         runner.begin_trait(y, check_missing=False)

@@ -172,7 +172,20 @@ int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, int nx, const
                           int64_t period, int n_sub, int n_batch, double* out, void* stream);
 
 /*
- * Decode rows to dense float32 [n_rows][n_pad] (count of allele 2, NaN = missing): the bit-exact
+ * Genotype coding of the packed buffers.  PLINK (default): the .bed body as it is.  VALUE: every 2-bit field holds the
+ * allele-2 count itself (00->0, 10->1, 11->2) and 3 for a missing call: the kernels then skip the three-instruction
+ * code -> count conversion they otherwise pay per dword in both contractions of both passes (-8 % GEMM 2 time).
+ * pyrhe_recode_rows converts a buffer IN PLACE (either direction, one streaming read + write: the decode contract of
+ * base.py:338-356 is unchanged, only where it is paid); pyrhe_engine_set_coding tells an engine which coding the
+ * `packed` arguments of its sketch / block_stats calls use.   Asynchronous on `stream` / immediate.
+ */
+#define PYRHE_CODING_PLINK 0
+#define PYRHE_CODING_VALUE 1
+int pyrhe_recode_rows(uint8_t* packed, int64_t n_rows, int64_t pitch, int to_coding, void* stream);
+int pyrhe_engine_set_coding(pyrhe_engine_t* e, int coding);
+
+/*
+ * Decode PLINK-coded rows to dense float32 [n_rows][n_pad] (count of allele 2, NaN = missing): the bit-exact
  * decode contract of bed_reader.read + the reference's flip (base.py:338-356).  Test/diagnostic entry
  * point; independent of any engine.   Asynchronous on `stream`.
  */

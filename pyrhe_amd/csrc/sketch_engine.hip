@@ -81,6 +81,21 @@ __device__ __forceinline__ uint32_t apply_fill(uint32_t v, uint32_t miss, int fi
     return fill == 0 ? v - miss : (fill == 2 ? v + miss : v);
 }
 
+// 16 genotypes of a packed dword -> allele-2 counts in the 2-bit value code.  VC = the buffer was recoded once by
+// pyrhe_recode_rows (00->0, 10->1, 11->2, 01 "missing"->3): the three VALU ops of value_code() are not paid per kernel
+// per pass.  MISSING: substitute `fill` (0/1/2) for missing calls.
+template <bool VC, bool MISSING>
+__device__ __forceinline__ uint32_t geno_values(uint32_t w, int fill) {
+    if (!VC) {
+        uint32_t v = value_code(w);
+        if (MISSING) v = apply_fill(v, missing_mask(w), fill);
+        return v;
+    }
+    if (!MISSING) return w;
+    const uint32_t m = w & (w >> 1) & 0x55555555u;          // 01 at the crumbs that hold 3
+    return fill == 0 ? w - m - (m << 1) : (fill == 1 ? w - (m << 1) : w - m);
+}
+
 // Two genotypes -> one register of two fp16 values.  Two variants:
 //  EXACT = false (precision f16): ONE v_and_b32.  For crumb position t = 0..3 of each 16-bit half of x,
 //     (x & (3 << 2t)) read as fp16 is the SUBNORMAL number c * 4^t * 2^-24 (exponent field 0).  The matrix
@@ -219,7 +234,7 @@ __global__ void prep_keepmask_kernel(const float* __restrict__ keep, int64_t n_p
 // a double-buffered LDS ring; the packed genotype words of step s+1 are in flight while step s is
 // decoded and multiplied (register prefetch, one barrier per step).
 // ------------------------------------------------------------------------------------------------
-template <int NTL, int PARTS, bool EXACT, bool MISSING, int GV = 0>
+template <int NTL, int PARTS, bool EXACT, bool MISSING, int GV = 0, bool VC = false>
 __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                     const int32_t* __restrict__ rows, int n_entries,
                                                     const float* __restrict__ fill,
@@ -292,8 +307,7 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const uint32_t w = d == 0 ? gg[t][ch].x : (d == 1 ? gg[t][ch].y : (d == 2 ? gg[t][ch].z : gg[t][ch].w));
-                    v[t] = value_code(w);
-                    if (MISSING) v[t] = apply_fill(v[t], missing_mask(w), fillv[t]);
+                    v[t] = geno_values<VC, MISSING>(w, fillv[t]);
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -410,7 +424,7 @@ __global__ void prep_rimg_i8_kernel(const float* __restrict__ R, const float* __
     if (chunk == 0 && d == 0 && limb == 0 && q == 0) scale[c] = s;
 }
 
-template <int NTL, bool MISSING, int GV = 0>
+template <int NTL, bool MISSING, int GV = 0, bool VC = false>
 __global__ __launch_bounds__(256, NTL == 1 ? 3 : 2) void gemm1_i8_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                        const int32_t* __restrict__ rows, int n_entries,
                                                        const float* __restrict__ fill,
@@ -479,8 +493,7 @@ __global__ __launch_bounds__(256, NTL == 1 ? 3 : 2) void gemm1_i8_kernel(const u
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const uint32_t w = d == 0 ? gg[t][ch].x : (d == 1 ? gg[t][ch].y : (d == 2 ? gg[t][ch].z : gg[t][ch].w));
-                    uint32_t v = value_code(w);
-                    if (MISSING) v = apply_fill(v, missing_mask(w), fillv[t]);
+                    const uint32_t v = geno_values<VC, MISSING>(w, fillv[t]);
                     constexpr uint32_t bm = GV ? 0x02020202u : 0x03030303u;
                     const int4v a = {(int)(v & bm), (int)((v >> 2) & bm), (int)((v >> 4) & bm), (int)((v >> 6) & bm)};
 #pragma unroll
@@ -812,7 +825,7 @@ __global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restr
 // in-order vector-memory queue.  MFMA u consumes crumb u of every dword: with the subnormal unpack the
 // accumulator of MFMA u carries the constant 4^(u&3) * 2^-24, removed once in the epilogue.
 // ------------------------------------------------------------------------------------------------
-template <int NTO, int PARTS, int IW, bool EXACT, bool MISSING, int GV = 0>
+template <int NTO, int PARTS, int IW, bool EXACT, bool MISSING, int GV = 0, bool VC = false>
 __global__ __launch_bounds__(256, 2) void gemm2_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                     const int32_t* __restrict__ rows32, int n_kb,
                                                     int kb_per_split, const float* __restrict__ fill,
@@ -895,8 +908,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const uint8_t* __restrict
             uint32_t v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                v[j] = value_code(ww[j][iw]);
-                if (MISSING) v[j] = apply_fill(v[j], missing_mask(ww[j][iw]), ff[j]);
+                v[j] = geno_values<VC, MISSING>(ww[j][iw], MISSING ? ff[j] : 0);
             }
             // x[p]: low halves of rows 2p (lo 16 bits) and 2p+1 (hi 16 bits) = samples 0..7 of the dword;
             // y[p]: high halves = samples 8..15.
@@ -1046,7 +1058,7 @@ __global__ void mid2_i8_kernel(const float* __restrict__ Wtmp, const float* __re
     if (kb == 0 && limb == 0 && q == 0) wscale[c] = s;
 }
 
-template <bool MISSING>
+template <bool MISSING, bool VC = false>
 __global__ __launch_bounds__(256, 1) void gemm2_i8_kernel(const uint8_t* __restrict__ packed, int64_t pitch,
                                                           const int32_t* __restrict__ rows64, int n_kb,
                                                           int kb_per_split, const float* __restrict__ fill,
@@ -1103,8 +1115,7 @@ __global__ __launch_bounds__(256, 1) void gemm2_i8_kernel(const uint8_t* __restr
             uint32_t v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] = value_code(ww[4 * p + r]);
-                if (MISSING) v[r] = apply_fill(v[r], missing_mask(ww[4 * p + r]), ff[4 * p + r]);
+                v[r] = geno_values<VC, MISSING>(ww[4 * p + r], MISSING ? ff[4 * p + r] : 0);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -1194,6 +1205,7 @@ __global__ void pad_rows_kernel(const int32_t* __restrict__ rows, int n, int n_p
     if (i < n_pad32) out[i] = i < n ? rows[i] : rows[0];
 }
 
+template <bool VC>
 __global__ void block_stats_kernel(const uint8_t* __restrict__ packed, int64_t pitch, int64_t n_rows,
                                    const uint32_t* __restrict__ keepmask, int32_t* __restrict__ out_sum,
                                    int32_t* __restrict__ out_nmiss) {
@@ -1206,8 +1218,8 @@ __global__ void block_stats_kernel(const uint8_t* __restrict__ packed, int64_t p
     for (int64_t w = lane; w < pitch / 4; w += 64) {
         const uint32_t km = keepmask[w];
         const uint32_t x = rp[w] & km;
-        const uint32_t miss = missing_mask(x);
-        const uint32_t v = value_code(x) - miss;   // missing -> 0
+        const uint32_t miss = VC ? (x & (x >> 1) & 0x55555555u) : missing_mask(x);
+        const uint32_t v = VC ? x - miss - (miss << 1) : value_code(x) - miss;   // missing -> 0
         sum += __popc(v & 0x55555555u) + 2 * __popc(v & 0xAAAAAAAAu);
         nm += __popc(miss);
     }
@@ -1218,6 +1230,21 @@ __global__ void block_stats_kernel(const uint8_t* __restrict__ packed, int64_t p
     if (lane == 0) {
         out_sum[row] = sum;
         out_nmiss[row] = nm;
+    }
+}
+
+// in-place recode of packed rows: PLINK code -> value code (00->0, 10->1, 11->2, 01->3) or back
+__global__ void recode_rows_kernel(uint32_t* __restrict__ p, int64_t n_words, int to_value) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = p[i];
+        uint32_t o;
+        if (to_value) {
+            o = value_code(w) | (missing_mask(w) << 1);          // missing (01) -> 01 | 10 = 11
+        } else {
+            const uint32_t hi = (w >> 1) & 0x55555555u, lo = w & 0x55555555u;
+            o = ((hi ^ lo) << 1) | hi;                           // 0->00, 1->10, 2->11, 3->01
+        }
+        p[i] = o;
     }
 }
 
@@ -1278,6 +1305,7 @@ struct pyrhe_engine {
     int precision = 0, parts = 1;
     bool exact = false;   // exact (normal-number) genotype unpack instead of the 1-op subnormal unpack
     bool i8 = false;      // GEMM 1 on int8 limbs (precision i8x3); GEMM 2 then runs the hi+lo fp16 form
+    bool vc = false;      // the caller's packed buffers hold the 2-bit VALUE code (pyrhe_recode_rows), not PLINK codes
     int n_sketch = 0, n_norm = 0, n_user = 0, ntl = 0, nto = 0;
     bool rhs_set = false;
     // device buffers
@@ -1553,10 +1581,10 @@ static void launch_gemm1(pyrhe_engine* e, const uint8_t* packed, const int32_t* 
                          int n_steps, int sps, int splits, hipStream_t stream) {
     dim3 grid((n + 255) / 256, splits);
     const size_t lds = (size_t)2 * 2 * 8 * PARTS * NTL * 1024;   // [2 buffers][2 chunks][8 PARTS NTL fragments][1 KiB]
-    if (fill)
-        gemm1_kernel<NTL, PARTS, EXACT, true, GV><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_steps, sps, e->P, splits > 1);
-    else
-        gemm1_kernel<NTL, PARTS, EXACT, false, GV><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_steps, sps, e->P, splits > 1);
+#define L1(MISS_, VC_) gemm1_kernel<NTL, PARTS, EXACT, MISS_, GV, VC_><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, e->rfrag, n_steps, sps, e->P, splits > 1)
+    if (e->vc) { if (fill) L1(true, true); else L1(false, true); }
+    else { if (fill) L1(true, false); else L1(false, false); }
+#undef L1
 }
 
 template <int NTO, int PARTS, int IW, bool EXACT, int GV = 0>
@@ -1564,10 +1592,10 @@ static void launch_gemm2(pyrhe_engine* e, const uint8_t* packed, int n_kb, int k
                          float* out, int mode, float* partial, hipStream_t stream, const SegTab& tab) {
     // segment mode (tab.nseg > 0): `splits` = number of segments, `kbps` = K blocks of the longest one (LDS row list)
     dim3 grid((unsigned)((e->n_pad + 1024 * IW - 1) / (1024 * IW)), splits);
-    if (fill)
-        gemm2_kernel<NTO, PARTS, IW, EXACT, true, GV><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial, tab);
-    else
-        gemm2_kernel<NTO, PARTS, IW, EXACT, false, GV><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial, tab);
+#define L2(MISS_, VC_) gemm2_kernel<NTO, PARTS, IW, EXACT, MISS_, GV, VC_><<<grid, 256, (size_t)kbps * 128, stream>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out, mode, partial, tab)
+    if (e->vc) { if (fill) L2(true, true); else L2(false, true); }
+    else { if (fill) L2(true, false); else L2(false, false); }
+#undef L2
 }
 
 // out[i] += sum_s partial[s][i]   (K-split partial sketches; float4 granularity)
@@ -1964,7 +1992,8 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         const int ua = splits > 1;
         if (e->i8) {
             const size_t lds = (size_t)2 * g1_ch * 12 * e->ntl * 1024;
-#define G1I(NTL_, MISS_, GV_) gemm1_i8_kernel<NTL_, MISS_, GV_><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua)
+#define G1I(NTL_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NTL_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua); \
+                                   else gemm1_i8_kernel<NTL_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua); } while (0)
             if (gv == 0) { if (e->ntl == 1) { if (fill) G1I(1, true, 0); else G1I(1, false, 0); } else { if (fill) G1I(2, true, 0); else G1I(2, false, 0); } }
             else         { if (e->ntl == 1) { if (fill) G1I(1, true, 1); else G1I(1, false, 1); } else { if (fill) G1I(2, true, 1); else G1I(2, false, 1); } }
 #undef G1I
@@ -2052,8 +2081,10 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         if (g2i8) {
             dim3 grid((unsigned)((e->n_pad + 1023) / 1024), splits);
             const size_t lds = (size_t)kbps * 256;
-            if (fill) gemm2_i8_kernel<true><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, mode, partial);
-            else gemm2_i8_kernel<false><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, mode, partial);
+#define L2I(MISS_, VC_) gemm2_i8_kernel<MISS_, VC_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, mode, partial)
+            if (e->vc) { if (fill) L2I(true, true); else L2I(false, true); }
+            else { if (fill) L2I(true, false); else L2I(false, false); }
+#undef L2I
         } else if (gv == 0) {
             if (e->parts == 2) { if (iw == 2) G2(1, 2, 2, true, 0); else if (e->nto == 1) G2(1, 2, 1, true, 0); else G2(2, 2, 1, true, 0); }
             else if (e->exact) { if (iw == 2) G2(1, 1, 2, true, 0); else if (e->nto == 1) G2(1, 1, 1, true, 0); else G2(2, 1, 1, true, 0); }
@@ -2268,7 +2299,8 @@ extern "C" int pyrhe_engine_block_stats(pyrhe_engine_t* e, const uint8_t* packed
     if (!e->rhs_set) return fail(PYRHE_ESTATE, "pyrhe_engine_set_rhs has not been called (keep mask unknown)");
     if (n_rows <= 0) return PYRHE_OK;
     HIPCHK(hipSetDevice(e->device));
-    block_stats_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(packed, e->pitch, n_rows, e->keepmask, out_sum, out_nmiss);
+    if (e->vc) block_stats_kernel<true><<<(unsigned)((n_rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(packed, e->pitch, n_rows, e->keepmask, out_sum, out_nmiss);
+    else block_stats_kernel<false><<<(unsigned)((n_rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(packed, e->pitch, n_rows, e->keepmask, out_sum, out_nmiss);
     HIPCHK(hipGetLastError());
     return PYRHE_OK;
 }
@@ -2397,6 +2429,23 @@ extern "C" int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, in
             loo_dots_reduce_kernel<<<(n_batch * 64 + 255) / 256, 256, 0, stream>>>(e->dots_partial, n_part, n_batch, nxt, nyt, a0, b0, nx, ny, out);
         }
     HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
+extern "C" int pyrhe_recode_rows(uint8_t* packed, int64_t n_rows, int64_t pitch, int to_coding, void* stream_) {
+    if (!packed) return fail(PYRHE_EINVAL, "NULL argument");
+    if (pitch <= 0 || pitch % 4) return fail(PYRHE_EINVAL, "pitch must be a positive multiple of 4");
+    if (to_coding != PYRHE_CODING_PLINK && to_coding != PYRHE_CODING_VALUE) return fail(PYRHE_EINVAL, "unknown coding %d", to_coding);
+    if (n_rows <= 0) return PYRHE_OK;
+    recode_rows_kernel<<<8192, 256, 0, (hipStream_t)stream_>>>(reinterpret_cast<uint32_t*>(packed), n_rows * (pitch / 4), to_coding == PYRHE_CODING_VALUE);
+    HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
+extern "C" int pyrhe_engine_set_coding(pyrhe_engine_t* e, int coding) {
+    if (!e) return fail(PYRHE_EINVAL, "NULL engine");
+    if (coding != PYRHE_CODING_PLINK && coding != PYRHE_CODING_VALUE) return fail(PYRHE_EINVAL, "unknown coding %d", coding);
+    e->vc = coding == PYRHE_CODING_VALUE;
     return PYRHE_OK;
 }
 

@@ -41,6 +41,8 @@ SYMBOLS = {
     "pyrhe_engine_join": (_i32, [_vp, _vp]),
     "pyrhe_engine_set_pipeline": (_i32, [_vp, _i32]),
     "pyrhe_decode_rows": (_i32, [_vp, _i64, _i64, _vp, _vp]),
+    "pyrhe_recode_rows": (_i32, [_vp, _i64, _i64, _i32, _vp]),
+    "pyrhe_engine_set_coding": (_i32, [_vp, _i32]),
     "pyrhe_sum_blocks": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
     "pyrhe_engine_loo_dots": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "pyrhe_synth_genotypes": (_i32, [_vp, _i64, _i64, _i64, _u64, _i64, _vp]),
@@ -136,6 +138,20 @@ def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 30) -
     return out
 
 
+CODINGS = {"plink": 0, "value": 1}
+
+
+def recode_rows(packed: torch.Tensor, to: str = "value") -> torch.Tensor:
+    """In-place recode of device rows between the PLINK code and the 2-bit value code (``pyrhe_recode_rows``); tell the
+    engines that will read the buffer with :meth:`SketchEngine.set_coding`."""
+    assert packed.dtype == torch.uint8 and packed.is_contiguous() and packed.dim() == 2
+    _require_gpu(packed.device)
+    with torch.cuda.device(packed.device):
+        _check(load_library().pyrhe_recode_rows(_ptr(packed), packed.shape[0], packed.shape[1], CODINGS[to],
+                                                _stream_ptr(packed.device)), "pyrhe_recode_rows")
+    return packed
+
+
 def synth_genotypes(n_rows: int, n_samples: int, seed: int, row0: int, device, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Device-side synthetic cohort rows (see ``pyrhe_synth_genotypes``)."""
     device = _require_gpu(device)
@@ -193,6 +209,7 @@ class SketchEngine:
         self.pitch = pitch_for(n_samples_orig)
         self.n_pad = 4 * self.pitch
         self.max_entries = int(max_entries)
+        self.coding = "plink"
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _check(self.lib.pyrhe_engine_create(self.device.index, self.n_keep, self.pitch, self.max_entries,
@@ -286,6 +303,11 @@ class SketchEngine:
                                                           _ptr(out_norm_dom), 1 if accumulate else 0, _stream_ptr(self.device)),
                    "pyrhe_engine_sketch_block_dom")
         return out_sketch, out_norm, out_sketch_dom, out_norm_dom
+
+    def set_coding(self, coding: str):
+        """How the ``packed`` buffers handed to this engine are coded: ``"plink"`` (default) or ``"value"``."""
+        _check(self.lib.pyrhe_engine_set_coding(self._h, CODINGS[coding]), "pyrhe_engine_set_coding")
+        self.coding = coding
 
     def set_async(self, enable: bool):
         """Defer the per-call join: consecutive blocks then overlap (GEMM 1 of block j+1 beside GEMM 2 of block j)."""

@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 from . import estimate as est
 from . import io as rio
-from .engine import SketchEngine, upload_packed
+from .engine import SketchEngine, recode_rows, upload_packed
 from .logger import Logger
 from .streaming import BlockPlan, SketchRunner, shard_ranges
 
@@ -120,8 +120,10 @@ class Base:
         r0 = self.plan.range(j0)[0] if j1 > j0 else 0
         r1 = self.plan.range(j1 - 1)[1] if j1 > j0 else 0
         self.geno_dev = upload_packed(packed[r0:r1], self.device)      # memmap slice -> HBM in pinned 1 GiB pieces
+        recode_rows(self.geno_dev, "value")                            # PLINK code -> allele counts, once, in place
         self.engine = SketchEngine(self.num_indv_original, self.num_indv, max_entries=self.plan.max_block,
                                    precision=precision, device=self.device, sub_snps=sub_snps)
+        self.engine.set_coding("value")
         self._runner = None
 
     # ---- plugin hooks of the reference (base.py:453-463)
@@ -332,6 +334,7 @@ class GENIE(Base):
         if n_cols > 30:      # GxE with covariates: [Z, UZ | y] and [e.Z, e.UZ | e.y] go through two engines
             self._engines.append(SketchEngine(self.num_indv_original, self.num_indv, max_entries=self.plan.max_block,
                                               precision=self.precision, device=self.device))
+            self._engines[-1].set_coding("value")
 
     def get_num_estimates(self):
         if self.genie_model == "G":

@@ -47,7 +47,7 @@ def test_synth_matches_cpu_twin(dev):
     assert not packed[:, plink.row_bytes(n):].any()          # padding bytes are zero
 
 
-def _engine_block_sketches(p, c, dev, precision, fill_by_block=None):
+def _engine_block_sketches(p, c, dev, precision, fill_by_block=None, coding="plink"):
     """Run the engine block by block; returns XXz [ne, jn, k, N], yXXy [ne, jn], colsums list."""
     from pyrhe_amd import engine
     N0 = c.n_indv
@@ -61,6 +61,9 @@ def _engine_block_sketches(p, c, dev, precision, fill_by_block=None):
     yp[0, torch.as_tensor(keep_idx, device=dev)] = torch.from_numpy(p.pheno[:, 0].astype(np.float32)).to(dev)
     eng.set_rhs(Zp, yp, keep)
     packed = engine.upload_packed(c.packed, dev)
+    if coding == "value":
+        engine.recode_rows(packed, "value")
+        eng.set_coding("value")
     XXz = np.zeros((p.nbin, p.n_jack, p.k, p.n_indv))
     yXXy = np.zeros((p.nbin, p.n_jack))
     colsums = []
@@ -108,8 +111,9 @@ def test_block_sketch_vs_reference_golden(dev, name, precision):
         assert np.array_equal(cs.astype(np.int64), exp)
 
 
+@pytest.mark.parametrize("coding", ["plink", "value"])
 @pytest.mark.parametrize("name", ["rhe_1bin_missing", "rhe_1bin_missing_mean"])
-def test_block_sketch_with_missing_calls(dev, name):
+def test_block_sketch_with_missing_calls(dev, name, coding):
     """Missing genotype calls + dropped individuals; fill values replayed from NumPy's stream (base.py:265-289)."""
     z = load_golden(name)
     p, c = oracle_problem(z)
@@ -125,7 +129,7 @@ def test_block_sketch_with_missing_calls(dev, name):
             if miss[:, m].any():
                 f[m] = Xi[miss[:, m], m][0]
         fills.append(f)
-    XXz, yXXy, _ = _engine_block_sketches(p, c, dev, "f16x2", fill_by_block=fills)
+    XXz, yXXy, _ = _engine_block_sketches(p, c, dev, "f16x2" if coding == "plink" else "i8x3", fill_by_block=fills, coding=coding)
     ref = z["ref_t0_XXz_blocks"].astype(np.float64)
     for j in range(p.n_jack):
         scale = np.abs(ref[0, j]).max()
@@ -238,3 +242,37 @@ def test_loo_dots_paths_vs_float64_reference(dev, nx, ny, n_sub, batch):
     lx = blk_rows(True)
     run(lx, lx)                                      # generic: leave-one-out Gram
     eng.close()
+
+
+def test_value_coding_recode_roundtrip_and_identical_results(dev):
+    """pyrhe_recode_rows: PLINK -> value code -> PLINK is the identity (missing calls included); the value code is the
+    allele count with 3 for missing; sketches, exact genotype sums and block statistics are IDENTICAL in both codings."""
+    from pyrhe_amd import engine
+    z = load_golden("rhe_1bin_missing")
+    p, c = oracle_problem(z)
+    raw = engine.upload_packed(c.packed, dev)
+    val = engine.recode_rows(raw.clone(), "value")
+    assert torch.equal(engine.recode_rows(val.clone(), "plink"), raw)
+    codes = plink.decode_codes(c.packed, c.n_indv)                  # PLINK 2-bit codes per (snp, sample)
+    want = np.array([0, 3, 1, 2], np.uint8)[codes]                   # 00->0, 01(missing)->3, 10->1, 11->2
+    got = plink.decode_codes(val.cpu().numpy()[:, : c.packed.shape[1]], c.n_indv)
+    assert np.array_equal(got, want)
+    outs = []
+    for coding, buf in (("plink", raw), ("value", val)):
+        eng = engine.SketchEngine(c.n_indv, p.n_indv, max_entries=p.n_snp, precision="i8x3", device=dev)
+        eng.set_coding(coding)
+        keep = eng.keep_vector(p.missing_indv)
+        gen = torch.Generator().manual_seed(3)
+        Z = torch.zeros((p.k, eng.n_pad), device=dev)
+        Z[:, : c.n_indv] = torch.randn((p.k, c.n_indv), generator=gen).to(dev)
+        Z *= keep
+        eng.set_rhs(Z, Z[:1].clone(), keep)
+        s_, nmiss = eng.block_stats(buf)
+        fill = (torch.arange(p.n_snp, device=dev) % 3).float()
+        ent = torch.arange(p.n_snp, dtype=torch.int32, device=dev)
+        sk, nm, cs = eng.sketch_block(buf, ent, [0, p.n_snp], fill=fill, want_colsum=True)
+        torch.cuda.synchronize()
+        outs.append((s_.clone(), nmiss.clone(), sk.clone(), nm.clone(), cs.clone()))
+        eng.close()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

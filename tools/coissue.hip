@@ -7,7 +7,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 template <int MODE>   // 0: MFMA only, 1: VALU only, 2: interleaved (4 MFMA then 20 VALU), 3: interleaved fine (1 MFMA, 5 VALU)
-__global__ __launch_bounds__(512) void k(float* out, int iters) {
+__global__ __launch_bounds__(1024) void k(float* out, int iters) {
     half8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x & 3); b[i] = (_Float16)1; }
     float4v acc[8];
@@ -46,7 +46,7 @@ int main() {
     float* o; hipMalloc(&o, 256 * 512 * 4 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const char* names[] = {"32 MFMA", "160 VALU", "32 MFMA + 160 VALU (4/20 groups)", "32 MFMA + 160 VALU (1/5 fine)"};
-    for (int waves = 1; waves <= 2; ++waves) for (int mode = 0; mode < 4; ++mode) {
+    for (int waves = 1; waves <= 4; ++waves) for (int mode = 0; mode < 4; ++mode) {
         const int iters = 4000;
         auto run = [&]() {
             const int th = 256 * waves;
@@ -56,7 +56,7 @@ int main() {
         run(); hipDeviceSynchronize();
         hipEventRecord(e0); run(); hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("%d wave(s)/SIMD  %-36s %.1f ns per loop body per wave  (%.0f cycles at 2.4 GHz)\n", waves, names[mode], ms * 1e6 / iters, ms * 1e6 / iters * 2.4);
+        printf("%d wave(s)/SIMD  %-36s %.1f ns per loop body per wave -> %.1f ns per body per SIMD\n", waves, names[mode], ms * 1e6 / iters, ms * 1e6 / iters / waves);
     }
     return 0;
 }
