@@ -84,12 +84,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU over RCCL ("nccl").  PYRHE_DIST_BACKEND=gloo is a rehearsal aid only: several ranks may then share
+    # one GPU (local_rank wraps around), which RCCL refuses.
+    backend = os.environ.get("PYRHE_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
     from pyrhe_amd import engine as eng_mod
@@ -153,7 +159,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev.index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):

@@ -436,15 +436,17 @@ class SketchRunner:
                 else:
                     wsum += A * float(jn - (self.j0 + jl_i))
         if self.world > 1:
-            self._allreduce(tot_A)
-            self._allreduce(tot_r)
-            if use_cov:
-                self._allreduce(tot_C)
-                if q4:   # U is linear: sum_j U(running_j) = U(sum_j (jn - j) XXz_j)  (float32 rounding order differs)
-                    self._allreduce(wsum)
-                    D_tot = self._apply_U(wsum, f32=True)
-                else:
-                    D_tot = self._apply_U(tot_A, f32=True)
+            # ONE all-reduce per pass: XXz | yXXy (| XXUz | the (jn - j)-weighted XXz of quirk Q4) packed in one buffer
+            parts = [tot_A, tot_r] + ([tot_C] if use_cov else []) + ([wsum] if q4 else [])
+            flat = torch.cat([t.reshape(-1) for t in parts])
+            self._allreduce(flat)
+            off = 0
+            for t in parts:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+            del flat
+            if use_cov:   # U is linear: sum_j U(running_j) = U(sum_j (jn - j) XXz_j)  (float32 rounding order differs)
+                D_tot = self._apply_U(wsum if q4 else tot_A, f32=True)
         self.tot_A, self.tot_C, self.tot_r, self.D_tot = tot_A, tot_C, tot_r, D_tot
         self.tot_sk = tot_A            # [n_est_g, k, n_pad] float64 (kept under the old name for callers)
 

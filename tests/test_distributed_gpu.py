@@ -1,0 +1,43 @@
+"""The driver's multi-GPU launch line rehearsed on ONE GPU: two ranks (gloo instead of RCCL, which refuses two ranks on one
+device) shard the jackknife blocks, all-reduce the accumulators, gather the leave-one-out systems -- sigma^2 and SEs must
+equal the single-process run of the same cohort."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--n-indv", "20000", "--n-snp", "20000", "--jn", "10", "--steps", "1", "--warmup", "1", "--verify",
+        "--no-cpu-baseline", "--no-alt"]
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _last_json(out: str) -> dict:
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("extra", [[], ["--n-bin", "4", "--n-cov", "3"]])
+def test_bench_two_ranks_equal_one_rank(extra):
+    env = dict(os.environ, PYRHE_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + ARGS + extra, cwd=REPO, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "2"] + ARGS + extra,
+                         cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = _last_json(one.stdout), _last_json(two.stdout)
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["scaling"] == "strong"
+    # the cross-rank float64 sum changes the summation order only
+    assert np.allclose(a["config"]["sigma_total"], b["config"]["sigma_total"], rtol=1e-9)
+    assert np.allclose(a["config"]["sigma_se"], b["config"]["sigma_se"], rtol=1e-7)
