@@ -270,7 +270,6 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
         for (int n = 0; n < NTL; ++n) acc[t][n] = (float4v){0.f, 0.f, 0.f, 0.f};
 
     uint4 g[2][4][CH];
-    half8 rs[LD];
     auto issue_g = [&](int s, uint4 (&gg)[4][CH]) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -278,31 +277,28 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
             for (int ch = 0; ch < CH; ++ch)
                 gg[t][ch] = *reinterpret_cast<const uint4*>(rowp[t] + (int64_t)s * (64 * CH) + 64 * ch);
     };
-    auto issue_r = [&](int s) {
+    // R image of a step -> LDS by LDS-DMA (see gemm1_i8_kernel): one contiguous 1-KiB fragment per wave-instruction
+    auto issue_r = [&](int s, int buf) {
         const half8* src = rfrag + (int64_t)s * (CH * FR * 64) + threadIdx.x;
+        half8* dst = rbuf + buf * (CH * FR * 64) + wave * 64;
 #pragma unroll
-        for (int i = 0; i < LD; ++i) rs[i] = src[i * 256];
-    };
-    auto stage_r = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < LD; ++i) rbuf[buf * (CH * FR * 64) + i * 256 + threadIdx.x] = rs[i];
+        for (int i = 0; i < LD; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
     };
     auto compute = [&](const uint4 (&gg)[4][CH], int buf) {
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
             const half8* rf = rbuf + buf * (CH * FR * 64) + ch * (FR * 64) + lane;
-            // all fragments of the chunk are read from LDS back to back (one latency), then consumed
-            half8 b[4][2][PARTS][NTL];
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
+            for (int d = 0; d < 4; ++d) {
+                half8 b[2][PARTS][NTL];
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int p = 0; p < PARTS; ++p)
 #pragma unroll
-                        for (int n = 0; n < NTL; ++n) b[d][h][p][n] = rf[(((d * 2 + h) * PARTS + p) * NTL + n) * 64];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
+                        for (int n = 0; n < NTL; ++n) b[h][p][n] = rf[(((d * 2 + h) * PARTS + p) * NTL + n) * 64];
                 uint32_t v[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -318,33 +314,42 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
                         for (int p = 0; p < PARTS; ++p)
 #pragma unroll
                             for (int n = 0; n < NTL; ++n)
-                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[d][h][p][n], acc[t][n], 0, 0, 0);
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[h][p][n], acc[t][n], 0, 0, 0);
                     }
                 }
             }
         }
     };
+    auto touch = [&](const uint4 (&gg)[4][CH]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch)
+                asm volatile("" ::"v"(gg[t][ch].x), "v"(gg[t][ch].y), "v"(gg[t][ch].z), "v"(gg[t][ch].w));
+    };
 
     // The host guarantees an even number of steps per split, so the ring needs no tail; the prefetch of the step
-    // after the last one is clamped (a harmless re-read) rather than branched around: a conditional load makes the
-    // compiler's s_waitcnt placement assume the short path and wait for the NEW loads on the hot one.
+    // after the last one is clamped (a harmless re-read) rather than branched around.  Order inside a step: touch
+    // the packed words of this step (the compiler's wait lands before the new loads), issue the LDS-DMA of the next R
+    // slice and the next packed words, compute, wait for the LDS-DMA only (counted vmcnt), raw barrier.
+    issue_r(s0, 0);
     issue_g(s0, g[0]);
-    issue_r(s0);
-    stage_r(0);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     for (int s = s0; s < s1; s += 2) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int nxt = min(s + k + 1, s1 - 1);
-            // R image first (L2-resident, needed at the end of this step), packed words last: waiting for the
-            // former then leaves the HBM loads of the next step in flight (the vector-memory queue is in-order).
-            issue_r(nxt);
+            touch(g[k]);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_r(nxt, k ^ 1);
             issue_g(nxt, g[k ^ 1]);
-            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE the MFMA block (LLVM sinks it otherwise)
+            __builtin_amdgcn_sched_barrier(0);
             compute(g[k], k);
             __builtin_amdgcn_sched_barrier(0);
-            stage_r(k ^ 1);
-            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * CH) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
     }
     // D: lane holds rows 4q + reg (entry), col r
