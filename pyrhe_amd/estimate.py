@@ -17,18 +17,30 @@ def solve_normal_equations(T: np.ndarray, q: np.ndarray, method: str = "QR") -> 
     raise ValueError("Unsupported method for solving linear equation")
 
 
+_controller = None
+
+
+def single_threaded_blas():
+    """Context manager pinning the host BLAS/LAPACK/OpenMP pools to one thread.  The host arithmetic of this package is
+    tiny ((ne+1)^2 solves, [blocks, ne, ne] scalings, one dot product of length N); on a 256-core host every multi-threaded
+    BLAS call that finds its pool asleep pays 50-100 ms to wake it (measured: pass 2 at 31 ms vs 100 ms)."""
+    global _controller
+    try:
+        from threadpoolctl import ThreadpoolController
+    except ImportError:
+        import contextlib
+        return contextlib.nullcontext()
+    if _controller is None:
+        _controller = ThreadpoolController()
+    return _controller.limit(limits=1)
+
+
 def solve_all(T: np.ndarray, q: np.ndarray, method: str = "QR") -> np.ndarray:
     """The jn+1 solves of one trait, ``T [jn+1, ne+1, ne+1]``, ``q [jn+1, ne+1]`` -> ``[jn+1, ne+1]``.  The systems are
     (ne+1) x (ne+1): the BLAS/LAPACK thread pool is pinned to one thread for the loop (on a 256-core host waking the
     pool costs tens of milliseconds, the solves themselves microseconds)."""
-    def run():
+    with single_threaded_blas():
         return np.array([solve_normal_equations(T[j], np.asarray(q[j]).reshape(-1, 1), method) for j in range(T.shape[0])])
-    try:
-        from threadpoolctl import threadpool_limits
-    except ImportError:
-        return run()
-    with threadpool_limits(limits=1):
-        return run()
 
 
 def jackknife_se(ests: np.ndarray, n_jack: int) -> list:

@@ -452,6 +452,11 @@ class SketchRunner:
 
     def pass2(self) -> Systems:
         """Leave-one-out normal equations where each block lives (base_streaming.py:110-144), gathered to every rank."""
+        from .estimate import single_threaded_blas
+        with single_threaded_blas():
+            return self._pass2()
+
+    def _pass2(self) -> Systems:
         plan, k, ne = self.plan, self.k, self.n_est
         jn, nb = plan.n_jack, plan.n_bin
         use_cov = self.cov is not None
@@ -603,9 +608,26 @@ class SketchRunner:
         b = self._dots(blk_rows, y, n_sub, batch)                  # rows evaluate to -blk
         return t + b, -b
 
+    def _to_host(self, t: torch.Tensor) -> np.ndarray:
+        """Device tensor -> NumPy through a cached pinned buffer (asynchronous copy, then an event poll)."""
+        if t.device.type != "cuda":
+            return t.numpy()
+        key = (tuple(t.shape), t.dtype)
+        if not hasattr(self, "_pinned"):
+            self._pinned = {}
+        buf = self._pinned.get(key)
+        if buf is None:
+            buf = self._pinned[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        buf.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        while not ev.query():
+            pass
+        return buf.numpy().copy()
+
     def _dots(self, x, y, n_sub, batch):
         """loo_dots with None rows (exact zeros) filtered out; float64 DEVICE tensor [batch, len(x), len(y)] -- nothing
-        here waits for the GPU (a blocking copy per call costs more than the kernels)."""
+        here waits for the GPU."""
         xi = [i for i, r in enumerate(x) if r is not None]
         yi = [i for i, r in enumerate(y) if r is not None]
         if not xi or not yi:
@@ -682,25 +704,39 @@ class SketchRunner:
             r = r - torch.cat(parts, dim=1)
         if self.n_nxe:
             r = torch.cat([r, nxe[2][None, :].expand(batch, 1)], dim=1)
-        Mf = torch.as_tensor(M_rows.astype(np.float64), device=dev)     # [batch, ne]
-        T = torch.zeros((batch, ne + 1, ne + 1), dtype=f64, device=dev)
-        q = torch.zeros((batch, ne + 1), dtype=f64, device=dev)
+        # one copy back: gram | tz | tk | r  -- no host->device traffic and no intermediate synchronisation in here; the
+        # division by the SNP counts is host arithmetic on [batch, ne, ne]
+        cols = [gram.reshape(batch, -1), r]
+        if tz is not None:
+            cols.append(tz.expand(batch, -1) if tz.shape[0] != batch else tz)
+        if tk is not None:
+            cols.append(tk.expand(batch, -1) if tk.shape[0] != batch else tk)
+        host = self._to_host(torch.cat(cols, dim=1))
+        gram_h = host[:, :ne * ne].reshape(batch, ne, ne)
+        r_h = host[:, ne * ne:ne * ne + ne]
+        off = ne * ne + ne
+        tz_h = tk_h = None
+        if tz is not None:
+            tz_h = host[:, off:off + ne]; off += ne
+        if tk is not None:
+            tk_h = host[:, off:off + ne]
+        Mf = M_rows.astype(np.float64)                            # [batch, ne]
+        T = np.zeros((batch, ne + 1, ne + 1))
+        q = np.zeros((batch, ne + 1))
         mm = Mf[:, :, None] * Mf[:, None, :]
-        zero = torch.zeros((), dtype=f64, device=dev)
-        T[:, :ne, :ne] = torch.where(mm != 0, gram / k / mm, zero)
-        tr = torch.full((batch, ne), float(self.N), dtype=f64, device=dev)       # rhe.py:24-26
-        if self.genie_model is not None and ne > nb:
-            tr[:, nb:] = tz[:, nb:] / (k * Mf[:, nb:])             # stochastic trace of a GxE / NxE kernel (genie.py:85-89)
-        if use_cov:
-            tr = tr - tk / (k * Mf)                                # base.py:614-615
-        q[:, :ne] = torch.where(Mf != 0, r / Mf, zero)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            T[:, :ne, :ne] = np.where(mm != 0, gram_h / k / mm, 0.0)
+            tr = np.full((batch, ne), float(self.N))              # rhe.py:24-26
+            if self.genie_model is not None and ne > nb:
+                tr[:, nb:] = tz_h[:, nb:] / (k * Mf[:, nb:])       # stochastic trace of a GxE / NxE kernel (genie.py:85-89)
+            if use_cov:
+                tr = tr - tk_h / (k * Mf)                          # base.py:614-615
+            q[:, :ne] = np.where(Mf != 0, r_h / Mf, 0.0)
         T[:, :ne, ne] = tr
         T[:, ne, :ne] = tr
         T[:, ne, ne] = self.N - (self.cov.shape[1] if use_cov else 0)
         q[:, ne] = yy
-        both = torch.cat([T.reshape(batch, -1), q], dim=1).cpu().numpy()         # the one blocking copy
-        n2 = (ne + 1) * (ne + 1)
-        return both[:, :n2].reshape(batch, ne + 1, ne + 1).copy(), both[:, n2:].copy()
+        return T, q
 
     def _stored_block(self, jl_i: int):
         sk, nm = [b[jl_i] for b in self.blocks_sk], [b[jl_i] for b in self.blocks_nm]

@@ -23,10 +23,24 @@ runner.begin_trait(y, check_missing=False)
 runner.pass1(); torch.cuda.synchronize()
 t0 = time.perf_counter(); runner.pass1(); torch.cuda.synchronize(); print("pass1 s", time.perf_counter() - t0)
 t0 = time.perf_counter(); runner.pass2(); torch.cuda.synchronize(); print("pass2 (first call) s", time.perf_counter() - t0)
+import gc
+if os.environ.get("GC_OFF"):
+    gc.disable()
+_gc_t = {}
+def _gc_cb(phase, info):
+    if phase == "start": _gc_t["t"] = time.perf_counter()
+    else:
+        dt = (time.perf_counter() - _gc_t["t"]) * 1e3
+        if dt > 5: print(f"   gc gen{info['generation']} took {dt:.1f} ms")
+gc.callbacks.append(_gc_cb)
+ts = []
+for _ in range(12):
+    t0 = time.perf_counter(); runner.pass2(); torch.cuda.synchronize(); ts.append(round((time.perf_counter() - t0) * 1e3, 1))
+print("pass2 x12 ms:", ts)
 pr = cProfile.Profile(); pr.enable()
 t0 = time.perf_counter(); runner.pass2(); torch.cuda.synchronize(); print("pass2 s", time.perf_counter() - t0)
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
+pstats.Stats(pr).sort_stats("tottime").print_stats(14)
 
 if os.environ.get("TRACE_DOTS"):
     sync = os.environ["TRACE_DOTS"] == "1"
