@@ -8,14 +8,17 @@
 // mu_s = mean, d_s = 1/sqrt(mu_s (1 - mu_s/2)):
 //     X^T R = D (G^T R - mu (1^T R))          GEMM 1  (reduce over samples)   + rank-1 correction
 //     X  V  = G (D V) - 1 (mu^T D V)          GEMM 2  (reduce over SNPs)      + rank-1 correction
-// Both GEMMs run on v_mfma_f32_16x16x32_f16 with G decoded in registers (0/1/2 are exact in fp16),
-// float32 accumulation, and R / W = D V fed as fp16 (one rounding, or a hi+lo split).
+// G is decoded in registers (0/1/2 are exact in int8 and fp16).  Default precision (i8x3): GEMM 1 on
+// v_mfma_i32_16x16x64_i8 with R as three int8 limbs and exact int32 accumulation, GEMM 2 on
+// v_mfma_f32_16x16x32_f16 with W = D V as a hi+lo fp16 pair; the fp16 forms of GEMM 1 serve f16x2 / f16.
 //
-// Kernels (per entry list = the SNP rows of one (block, bin, sub-block)):
-//   gemm1_kernel : P[e][c]   = sum_i G[i, row(e)] * Rh[i][c]        (+ exact column sums via a ones column)
-//   mid1_kernel  : mu, d, V = d (P/s - mu csum), norm columns -> sum V^2, W = d V (fp32) + column max
-//   mid2_kernel  : W -> fp16 MFMA operand image (per-column power-of-two scale), corr = mu^T Wh
-//   gemm2_kernel : out[c][i] (+)= keep[i] * (sum_e G[i, row(e)] * Wh[e][c] - corr[c]) / s_c
+// Kernels (a call = one jackknife block; several bins share ONE GEMM 1, see SegTab):
+//   gemm1(_i8)_kernel : P[e][c] = sum_i G[i, row(e)] * R[i][c]      (+ exact column sums via a ones column)
+//   mid1_kernel  : mu, d, V = d (P/s - mu csum), norm columns -> sum V^2, W = d V (fp32) + column max, per segment
+//   mid2_kernel  : W -> fp16 MFMA operand image (per-column power-of-two scale), corr = mu^T Wh, per segment
+//   gemm2_kernel : out[c][i] (+)= keep[i] * (sum_e G[i, row(e)] * Wh[e][c] - corr[c]) / s_c   (blockIdx.y = segment)
+//   sum_blocks / loo_dots / blk_fixed_dots / blk_self_gram : aggregate and the leave-one-out normal equations
+//   recode_rows  : PLINK code -> 2-bit value code, once per cohort (template flag VC in the GEMM kernels)
 //
 // MFMA operand maps used (guide: cdna_hip_programming.md section 3):
 //   A: lane l holds A[row l&15][k = 8 (l>>4) + j], j = 0..7;  B: lane l holds B[k = 8 (l>>4) + j][col l&15];
