@@ -346,6 +346,7 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const uint8_t* __restrict__ 
             touch(g[k]);
             __builtin_amdgcn_sched_barrier(0);
             issue_r(nxt, k ^ 1);
+            __builtin_amdgcn_sched_barrier(0);      // the counted vmcnt below relies on: LDS-DMAs first, packed words after
             issue_g(nxt, g[k ^ 1]);
             __builtin_amdgcn_sched_barrier(0);
             compute(g[k], k);
@@ -533,6 +534,7 @@ __global__ __launch_bounds__(256, NTL == 1 ? 3 : 2) void gemm1_i8_kernel(const u
             touch(g[k]);
             __builtin_amdgcn_sched_barrier(0);
             issue_r(nxt, k ^ 1);
+            __builtin_amdgcn_sched_barrier(0);      // the counted vmcnt below relies on: LDS-DMAs first, packed words after
             issue_g(nxt, g[k ^ 1]);
             __builtin_amdgcn_sched_barrier(0);
             compute(g[k], k);
