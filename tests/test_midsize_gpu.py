@@ -139,3 +139,55 @@ def test_pass2_device_assembly_equals_materialised_torch_path(case):
         assert np.abs(sa - sb).max() <= 1e-5 * np.abs(sb).max()
     for e_ in engs:
         e_.close()
+
+
+def test_full_sample_count_value_coding_segments_and_dots():
+    """At N = 500 000 (the bench's row length, 32-bit offsets near their limits): value-coded == PLINK-coded results bit
+    for bit; several bins in one call == one call per bin; pyrhe_engine_loo_dots over 10 x 500 736-element rows (all
+    three kernel paths) == float64 torch."""
+    from pyrhe_amd import engine
+    from pyrhe_amd.engine import Row
+    dev = torch.device("cuda", 0)
+    n, m, k = 500_000, 768, 10
+    geno = engine.synth_genotypes(m, n, SEED, 3, dev)
+    eng = engine.SketchEngine(n, n, m, device=dev)
+    keep = eng.keep_vector()
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    Z = torch.zeros((k, eng.n_pad), device=dev)
+    Z[:, :n] = torch.randn((k, n), generator=gen).to(dev)
+    y = torch.zeros((1, eng.n_pad), device=dev)
+    y[0, :n] = torch.randn(n, generator=gen).to(dev)
+    eng.set_rhs(Z, y, keep)
+    ent = torch.arange(m, dtype=torch.int32, device=dev)
+    offs = [0, 100, 100, 433, m]
+    sk, nm, cs = eng.sketch_block(geno, ent, offs, want_colsum=True)
+    # one call per bin
+    for b in range(4):
+        if offs[b + 1] == offs[b]:
+            assert not sk[b].any()
+            continue
+        s1, n1, _ = eng.sketch_block(geno, ent[offs[b]:offs[b + 1]].contiguous(), [0, offs[b + 1] - offs[b]])
+        assert (sk[b] - s1[0]).abs().max().item() <= 2e-6 * s1.abs().max().item()
+        assert torch.allclose(nm[b], n1[0], rtol=1e-6)
+    # value coding: identical bits
+    gv = engine.recode_rows(geno.clone(), "value")
+    eng.set_coding("value")
+    sk2, nm2, cs2 = eng.sketch_block(gv, ent, offs, want_colsum=True)
+    assert torch.equal(sk, sk2) and torch.equal(cs, cs2)
+    assert torch.allclose(nm, nm2, rtol=1e-13, atol=0)          # float64 atomics across workgroups: order-dependent last bits
+    # leave-one-out dots on bench-length rows: rows = whole-data (float64) minus the 4 "block" sketches (float32)
+    tot = sk.double().sum(0).contiguous()                      # [k, n_pad]
+    rows = [Row(tot, sk[0], None, sk.stride(0))]
+    got = eng.loo_dots(rows, rows, eng.n_pad, k, 4)
+    blk = [Row(None, sk[0], None, sk.stride(0))]
+    got_fixed = eng.loo_dots(blk, [Row(tot)], eng.n_pad, k, 4)
+    got_self = eng.loo_dots(blk, blk, eng.n_pad, k, 4)
+    for z in range(4):
+        loo = tot - sk[z].double()
+        ref = (loo * loo).sum().item()
+        assert abs(got[z, 0, 0].item() - ref) <= 1e-12 * abs(ref)
+        ref_f = -(sk[z].double() * tot).sum().item()
+        assert abs(got_fixed[z, 0, 0].item() - ref_f) <= 1e-11 * abs(ref_f) + 1e-6
+        ref_s = (sk[z].double() ** 2).sum().item()
+        assert abs(got_self[z, 0, 0].item() - ref_s) <= 1e-11 * abs(ref_s) + 1e-6
+    eng.close()
