@@ -203,7 +203,22 @@ def main():
             traffic = tj["kernels"][key]["bytes"]
     except Exception:
         traffic = None
+    # matrix-core work of the dominant kernel as issued (16-column tiles, all limbs / parts), beside the byte roofline:
+    # GEMM 2 is bound by instruction issue (matrix + unpack instructions do not overlap), not by HBM
+    n_pad = engine.n_pad
+    tiles_in = (engine.n_sketch + engine.n_norm + 1 + 15) // 16              # + the ones column
+    tiles_out = max(1, (engine.n_sketch + 15) // 16)
+    rows_per_launch = local_snps / launches
+    if dom == "gemm2_kernel":
+        parts = 1 if args.precision in ("f16", "f16e") else 2
+        mfma_ops, mfma_peak = rows_per_launch * 2.0 * n_pad * 16 * tiles_out * parts, 2500.0       # fp16 dense TFLOP/s
+    else:
+        parts = {"i8x3": 3, "f16x2": 2}.get(args.precision, 1)
+        mfma_ops = rows_per_launch * 2.0 * n_pad * 16 * tiles_in * parts
+        mfma_peak = 5000.0 if args.precision == "i8x3" else 2500.0                                 # int8 dense TOP/s
+    mfma_tops = mfma_ops / (dom_ms / launches * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "mfma_tops_issued": round(mfma_tops, 1), "mfma_frac": round(mfma_tops / mfma_peak, 4),
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(dom_ms / launches, 4),
                 "gemm1_ms_per_step": round(g1 / args.steps, 3), "gemm2_ms_per_step": round(g2 / args.steps, 3),
