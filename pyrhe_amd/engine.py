@@ -120,21 +120,32 @@ def _require_gpu(device) -> torch.device:
     return device
 
 
-def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 30) -> torch.Tensor:
+def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28) -> torch.Tensor:
     """Host ``[m, ceil(N/4)]`` uint8 rows (a NumPy array or a memory-mapped ``.bed`` body) -> device ``[m, pitch]``,
-    zero padded.  The rows are never decoded on the host; they are copied in ``chunk_bytes`` pieces through a pinned
-    staging buffer so a memory-mapped 100-GB file needs neither 100 GB of RAM nor one giant copy."""
+    zero padded.  The rows are never decoded on the host; they go through two pinned staging buffers of ``chunk_bytes``
+    (the host-side copy of piece i+1 overlaps the transfer of piece i), so a memory-mapped 100-GB file needs neither
+    100 GB of RAM nor one giant copy."""
     device = _require_gpu(device)
     m, rb = packed_rows.shape
     pitch = (rb + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
     out = torch.zeros((m, pitch), dtype=torch.uint8, device=device)
+    if m == 0:
+        return out
     rows_per = max(1, chunk_bytes // max(rb, 1))
-    staging = torch.empty((min(rows_per, max(m, 1)), rb), dtype=torch.uint8).pin_memory() if m else None
-    for r0 in range(0, m, rows_per):
-        r1 = min(r0 + rows_per, m)
-        staging[: r1 - r0].numpy()[...] = packed_rows[r0:r1]
-        out[r0:r1, :rb].copy_(staging[: r1 - r0], non_blocking=True)
-        torch.cuda.current_stream(device).synchronize()          # the staging buffer is reused
+    staging = [torch.empty((min(rows_per, m), rb), dtype=torch.uint8).pin_memory() for _ in range(2 if m > rows_per else 1)]
+    done = [None, None]
+    with torch.cuda.device(device):
+        for i, r0 in enumerate(range(0, m, rows_per)):
+            r1 = min(r0 + rows_per, m)
+            buf = staging[i % len(staging)]
+            if done[i % 2] is not None:
+                done[i % 2].synchronize()                     # the transfer that last used this buffer
+            buf[: r1 - r0].numpy()[...] = packed_rows[r0:r1]
+            out[r0:r1, :rb].copy_(buf[: r1 - r0], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            done[i % 2] = ev
+        torch.cuda.current_stream(device).synchronize()
     return out
 
 
