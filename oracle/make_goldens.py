@@ -86,6 +86,11 @@ CASES = [
     # (StreamingRHE without covariates raises AttributeError in the reference's aggregate, base_streaming.py:29)
     dict(name="srhe_2bin_missing_cov", cohort=dict(n_indv=403, n_snp=240, seed=25, nbin=2, missing_geno=0.02, missing_pheno=5, with_cov=3),
          model="StreamingRHE", kw=dict(num_jack=10, num_random_vec=10, seed=3)),
+    # num_random_vec beyond one engine pass (30 right-hand columns): the groups Z and UZ are split over three passes
+    dict(name="rhe_2bin_cov_k35", cohort=dict(n_indv=403, n_snp=240, seed=26, nbin=2, with_cov=3), model="RHE",
+         kw=dict(num_jack=10, num_random_vec=35, seed=14)),
+    dict(name="genie_gxe_k33", cohort=dict(n_indv=403, n_snp=240, seed=27, nbin=1, with_env=True), model="GENIE",
+         kw=dict(num_jack=10, num_random_vec=33, seed=15, genie_model="G+GxE+NxE")),
     dict(name="rhe_1bin_missing", cohort=dict(n_indv=403, n_snp=240, seed=14, missing_geno=0.02, missing_pheno=5),
          model="RHE", kw=dict(num_jack=10, num_random_vec=10, seed=3)),
     dict(name="rhe_1bin_missing_mean", cohort=dict(n_indv=403, n_snp=240, seed=14, missing_geno=0.02, missing_pheno=5),

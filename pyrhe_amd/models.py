@@ -25,7 +25,7 @@ from . import estimate as est
 from . import io as rio
 from .engine import SketchEngine, recode_rows, upload_packed
 from .logger import Logger
-from .streaming import BlockPlan, SketchRunner, shard_ranges
+from .streaming import n_engines_needed, BlockPlan, SketchRunner, shard_ranges
 
 
 class Base:
@@ -121,10 +121,22 @@ class Base:
         r1 = self.plan.range(j1 - 1)[1] if j1 > j0 else 0
         self.geno_dev = upload_packed(packed[r0:r1], self.device)      # memmap slice -> HBM in pinned 1 GiB pieces
         recode_rows(self.geno_dev, "value")                            # PLINK code -> allele counts, once, in place
-        self.engine = SketchEngine(self.num_indv_original, self.num_indv, max_entries=self.plan.max_block,
-                                   precision=precision, device=self.device, sub_snps=sub_snps)
-        self.engine.set_coding("value")
+        self._sub_snps = sub_snps
+        self.engine = self._new_engine()
+        self._engines = [self.engine]
+        self._grow_engines(has_gxe=False)
         self._runner = None
+
+    def _new_engine(self) -> SketchEngine:
+        eng = SketchEngine(self.num_indv_original, self.num_indv, max_entries=self.plan.max_block,
+                           precision=self.precision, device=self.device, sub_snps=self._sub_snps)
+        eng.set_coding("value")
+        return eng
+
+    def _grow_engines(self, has_gxe: bool):
+        """One engine per pass of at most 30 right-hand columns (num_random_vec, covariates and G x E decide how many)."""
+        while len(self._engines) < n_engines_needed(self.num_random_vec, self.use_cov, has_gxe):
+            self._engines.append(self._new_engine())
 
     # ---- plugin hooks of the reference (base.py:453-463)
     def get_num_estimates(self):
@@ -134,7 +146,7 @@ class Base:
         return self.len_bin
 
     def _make_runner(self) -> SketchRunner:
-        return SketchRunner(self.engine, self.geno_dev, self.plan, self.local_blocks, n_orig=self.num_indv_original,
+        return SketchRunner(self._engines, self.geno_dev, self.plan, self.local_blocks, n_orig=self.num_indv_original,
                             missing_indv=self.missing_indv, Z=self.all_zb, cov=self.cov_matrix, env=self.env,
                             genie_model=self.genie_model, impute=self.geno_impute_methods, seed=self.seed,
                             streaming=self.streaming, compat=self.compat, recompute_pass2=self.recompute_pass2,
@@ -270,7 +282,7 @@ class RHE_DOM(Base):
         return np.concatenate([self.len_bin, self.len_bin])
 
     def _make_runner(self) -> SketchRunner:
-        return SketchRunner(self.engine, self.geno_dev, self.plan, self.local_blocks, n_orig=self.num_indv_original,
+        return SketchRunner(self._engines, self.geno_dev, self.plan, self.local_blocks, n_orig=self.num_indv_original,
                             missing_indv=self.missing_indv, Z=self.all_zb, cov=self.cov_matrix, impute=self.geno_impute_methods,
                             seed=self.seed, streaming=self.streaming, compat=self.compat, recompute_pass2=self.recompute_pass2,
                             rng_prefix_draws=self._rng_prefix, dom=True)
@@ -328,13 +340,7 @@ class GENIE(Base):
         self.genie_model = genie_model
         self.log._log(f"Number of environments: {self.num_env}")
         self.log._log(f"GENIE model: {self.genie_model}")
-        has_gxe = genie_model in ("G+GxE", "G+GxE+NxE")
-        n_cols = (2 if self.use_cov else 1) * self.num_random_vec * (2 if has_gxe else 1) + (2 if has_gxe else 1)
-        self._engines = [self.engine]
-        if n_cols > 30:      # GxE with covariates: [Z, UZ | y] and [e.Z, e.UZ | e.y] go through two engines
-            self._engines.append(SketchEngine(self.num_indv_original, self.num_indv, max_entries=self.plan.max_block,
-                                              precision=self.precision, device=self.device))
-            self._engines[-1].set_coding("value")
+        self._grow_engines(has_gxe=genie_model in ("G+GxE", "G+GxE+NxE"))   # e.g. [Z, UZ | y, e.y] and [e.Z, e.UZ]
 
     def get_num_estimates(self):
         if self.genie_model == "G":

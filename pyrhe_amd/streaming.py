@@ -97,6 +97,35 @@ class Systems:
     M: np.ndarray        # [jn+1, ne]
 
 
+MAX_ENGINE_COLS = 30            # PYRHE_MAX_COLS of include/pyrhe_sketch.h
+
+
+def plan_passes(k: int, n_groups: int, n_norm: int):
+    """Distribute ``n_groups`` groups of ``k`` sketch columns (Z, UZ, e.Z, e.UZ) and ``n_norm`` norm columns (all in
+    pass 0) over engine passes of at most 30 right-hand columns.  A group stays whole when it fits into the current
+    pass or into a fresh one; only groups wider than a pass (num_random_vec > 30 - n_norm) are split.
+    Returns, per pass, a list of chunks ``(group index, first column s0, number of columns)``."""
+    passes, free = [[]], [MAX_ENGINE_COLS - n_norm]
+    for g in range(n_groups):
+        if k <= free[-1]:
+            passes[-1].append((g, 0, k)); free[-1] -= k
+        elif k <= MAX_ENGINE_COLS:
+            passes.append([(g, 0, k)]); free.append(MAX_ENGINE_COLS - k)
+        else:
+            s0 = 0
+            while s0 < k:
+                if free[-1] == 0:
+                    passes.append([]); free.append(MAX_ENGINE_COLS)
+                nc = min(free[-1], k - s0)
+                passes[-1].append((g, s0, nc)); free[-1] -= nc
+                s0 += nc
+    return passes
+
+
+def n_engines_needed(k: int, use_cov: bool, has_gxe: bool) -> int:
+    return len(plan_passes(k, (2 if use_cov else 1) * (2 if has_gxe else 1), 2 if has_gxe else 1))
+
+
 class SketchRunner:
     """Pass 1 (sketch every local block, accumulate, all-reduce) and pass 2 (leave-one-out systems).
 
@@ -202,41 +231,49 @@ class SketchRunner:
             y64 = y64 - W @ (np.linalg.pinv(W.T @ W) @ (W.T @ y64))
         self.y_res = y64
         ypad = self._pad_cols(torch.from_numpy(y64[None, :]))
-        g_groups = [self.Z64] + ([self.UZ64] if use_cov else [])
-        passes = [(g_groups, [ypad])]
+        names, groups, norms = ["Z"], [self.Z64], [ypad]
+        if use_cov:
+            names.append("UZ"); groups.append(self.UZ64)
         if self.n_gxe:
             e = self.env_pad
-            e_groups = [self.Z64 * e] + ([self.UZ64 * e] if use_cov else [])
-            passes.append((e_groups, [ypad * e]))
-        max_cols = 30
-        total = sum(sum(g.shape[0] for g in gs) + len(ns) for gs, ns in passes)
-        if len(passes) == 2 and total <= max_cols:
-            passes = [(passes[0][0] + passes[1][0], passes[0][1] + passes[1][1])]
-        if len(passes) > len(self.engs):
-            raise RuntimeError(f"{total} right-hand columns need {len(passes)} engines, {len(self.engs)} given")
-        # where each logical group lives: (pass index, first sketch column) ; norm: (pass index, column)
-        self.loc = {}
-        self.pass_shapes = []
-        for pi, (gs, ns) in enumerate(passes):
-            sk = torch.cat(gs, dim=0).to(torch.float32)
-            nm = torch.cat(ns, dim=0).to(torch.float32)
-            self.engs[pi].set_rhs(sk, nm, self.keep)
-            self.pass_shapes.append((sk.shape[0], nm.shape[0]))
+            names.append("eZ"); groups.append(self.Z64 * e)
+            if use_cov:
+                names.append("eUZ"); groups.append(self.UZ64 * e)
+            norms.append(ypad * e)
         k = self.k
-        ng = len(g_groups)
-        self.loc["Z"], self.loc["y"] = (0, 0), (0, 0)
-        if use_cov:
-            self.loc["UZ"] = (0, k)
+        passes = plan_passes(k, len(groups), len(norms))
+        if len(passes) > len(self.engs):
+            raise RuntimeError(f"{len(groups)} groups of {k} right-hand columns need {len(passes)} engines, "
+                               f"{len(self.engs)} given")
+        # where each logical group lives: a list of chunks (pass, first engine column, first group column s0, count);
+        # norm columns: (pass, column).  `breaks`: the common refinement of all chunk boundaries (pass 2 walks it).
+        self.loc = {n: [] for n in names}
+        self.pass_shapes = []
+        breaks = {0, k}
+        for pi, chunks in enumerate(passes):
+            col, parts = 0, []
+            for g, s0, nc in chunks:
+                self.loc[names[g]].append((pi, col, s0, nc))
+                parts.append(groups[g][s0:s0 + nc])
+                breaks.update((s0, s0 + nc))
+                col += nc
+            sk = torch.cat(parts, dim=0).to(torch.float32) if parts else None
+            nm = torch.cat(norms, dim=0).to(torch.float32) if pi == 0 else None
+            self.engs[pi].set_rhs(sk, nm, self.keep)
+            self.pass_shapes.append((col, len(norms) if pi == 0 else 0))
+        self.loc["y"] = (0, 0)
         if self.n_gxe:
-            if len(passes) == 1:
-                self.loc["eZ"], self.loc["ey"] = (0, ng * k), (0, 1)
-                if use_cov:
-                    self.loc["eUZ"] = (0, (ng + 1) * k)
-            else:
-                self.loc["eZ"], self.loc["ey"] = (1, 0), (1, 0)
-                if use_cov:
-                    self.loc["eUZ"] = (1, k)
+            self.loc["ey"] = (0, 1)
         self.n_pass = len(passes)
+        bl = sorted(breaks)
+        self.intervals = [(bl[i], bl[i + 1] - bl[i]) for i in range(len(bl) - 1)]
+
+    def _loc_at(self, name: str, s0: int):
+        """(pass, engine column) holding column ``s0`` of group ``name``."""
+        for p_, c0, g0, nc in self.loc[name]:
+            if g0 <= s0 < g0 + nc:
+                return p_, c0 + (s0 - g0)
+        raise KeyError((name, s0))
 
     # ---- imputation fill values ---------------------------------------------------------------
     def _block_rows(self, j: int) -> torch.Tensor:
@@ -352,8 +389,9 @@ class SketchRunner:
 
     # ---- estimate-level views of one block's (or the total's) engine outputs ----------------------
     def _group(self, sk_list, name):
-        p, c0 = self.loc[name]
-        return sk_list[p][:, c0:c0 + self.k]
+        """All k columns of a group ``[..., k, n_pad]`` from per-pass engine outputs (a view when the group is whole)."""
+        parts = [sk_list[p_][:, c0:c0 + nc] for p_, c0, _, nc in self.loc[name]]
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
     def _block_estimates(self, sk_list, nm_list, skd_list=None, nmd_list=None):
         """A = XXz, C = XXUz ``[ne_g, k, n_pad]`` and r = yXXy ``[ne_g]`` of the genotype-derived estimates (G bins,
@@ -561,17 +599,18 @@ class SketchRunner:
         return Systems(np.stack([t[1] for t in local] + [T_tot]), np.stack([t[2] for t in local] + [q_tot]), M)
 
     # ---- on-device normal equations ---------------------------------------------
-    def _loo_rows(self, tot, store, group, egroup, nxe_row):
-        """Row descriptors of the ne estimates of one accumulator family (XXz: group "Z"/"eZ", XXUz: "UZ"/"eUZ"):
-        whole-data slot minus the stored block sketch (``store`` None: whole-data slot alone)."""
+    def _loo_rows(self, tot, store, group, egroup, nxe_row, s0, nc):
+        """Row descriptors, restricted to probe columns ``s0 .. s0+nc-1``, of the ne estimates of one accumulator family
+        (XXz: group "Z"/"eZ", XXUz: "UZ"/"eUZ"): whole-data slot minus the stored block sketch (``store`` None: the
+        whole-data slot alone)."""
         from .engine import Row
-        nb, k = self.plan.n_bin, self.k
+        nb = self.plan.n_bin
         sk, skd = (store[0], store[2]) if store is not None else (None, None)
 
         def view(lst, name, b):
-            p_, c0 = self.loc[name]
+            p_, c0 = self._loc_at(name, s0)
             t = lst[p_]                                            # [batch, nb, n_sketch, n_pad] float32
-            return t[0, b, c0:c0 + k], t.stride(0)
+            return t[0, b, c0:c0 + nc], t.stride(0)
         rows = []
         for a in range(tot.shape[0]):
             blk, stride, mul = None, 0, None
@@ -583,17 +622,17 @@ class SketchRunner:
                 else:
                     blk, stride = view(sk, egroup, a - nb)
                     mul = self.env32
-            rows.append(Row(tot[a], blk, mul, stride))
+            rows.append(Row(tot[a, s0:s0 + nc], blk, mul, stride))
         if nxe_row is not None:
-            rows.append(Row(nxe_row))
+            rows.append(Row(nxe_row[s0:s0 + nc]))
         return rows
 
-    def _sub_rows(self, rows):
-        """The k sub-rows (one probe vector each, length n_pad) of every row, for projections onto the covariates."""
+    def _sub_rows(self, rows, nc):
+        """The nc sub-rows (one probe vector each, length n_pad) of every row, for projections onto the covariates."""
         from .engine import Row
         out = []
         for r in rows:
-            for s_ in range(self.k):
+            for s_ in range(nc):
                 out.append(Row(None if r.tot is None else r.tot[s_], None if r.blk is None else r.blk[s_], r.mul, r.stride))
         return out
 
@@ -636,9 +675,13 @@ class SketchRunner:
         if len(xi) == len(x) and len(yi) == len(y):
             return res
         out = torch.zeros((batch, len(x), len(y)), dtype=torch.float64, device=self.device)
-        ix = torch.as_tensor(xi, device=self.device)
-        iy = torch.as_tensor(yi, device=self.device)
-        out[:, ix[:, None], iy[None, :]] = res
+        if not hasattr(self, "_idx_cache"):
+            self._idx_cache = {}
+        key = (tuple(xi), tuple(yi))
+        if key not in self._idx_cache:      # uploaded once per pattern: no host->device copy on the steady path
+            self._idx_cache[key] = (torch.as_tensor(xi, device=self.device)[:, None], torch.as_tensor(yi, device=self.device)[None, :])
+        ix, iy = self._idx_cache[key]
+        out[:, ix, iy] = res
         return out
 
     def _loo_systems(self, tots, nxe, store, batch, M_rows, yy):
@@ -657,35 +700,44 @@ class SketchRunner:
                 nC = torch.zeros_like(nxe[0][0]); nD = torch.zeros_like(nxe[0][0])
                 nC[k - 1] = nxe[1][0, k - 1]
                 nD[k - 1] = self._apply_U(nxe[0][0, k - 1], f32=True)
-        A = self._loo_rows(tot_A, store, "Z", "eZ", nA)
-        # <XXz_a, XXz_b> of the slot, expanded around the whole-data rows: (t - b)(t - b)^T = tt - bt - (bt)^T + bb.
-        # The whole-data rows are then read once per 64 block rows (matrix-core path) instead of once per block.
-        A_tot = [Row(r.tot) for r in A]
-        A_blk = [None if r.blk is None else Row(None, r.blk, r.mul, r.stride) for r in A]
-        fixed = list(A_tot)
-        if self.genie_model is not None:
-            fixed.append(Row(self.Z64))
+        # Every inner product is a sum over probe columns: walk the column intervals on which each group sits in one
+        # engine pass (a single interval unless num_random_vec exceeds what a pass holds) and add the pieces up.
+        gram = tz = tk = gCD = None
+        PA_l, PbA_l, PC_l = [], [], []
         if use_cov:
-            fixed.append(Row(self.UZ64))
-        bpart = self._dots(A_blk, fixed, k, batch)                # block rows evaluate to -blk: -<b_a, fixed>
-        g = self._dots(A_tot, fixed, k, 1) + bpart
-        gram = g[:, :, :ne] + bpart[:, :, :ne].transpose(1, 2) + self._dots(A_blk, A_blk, k, batch)
-        col = ne
-        tz = tk = None
-        if self.genie_model is not None:
-            tz = g[:, :, col]; col += 1
-        if use_cov:
-            tk = g[:, :, col]
-            Cr = self._loo_rows(tot_C, store, "UZ", "eUZ", nC)
-            Dr = [Row(D_tot[a]) for a in range(D_tot.shape[0])] + ([Row(nD)] if nD is not None else [])
-            gCD = self._lin_dots(Cr, Dr, k, batch)[0]             # <XXUz_a (LOO), UXXz_b (whole data)>
             Wr = [Row(self.WT64[m]) for m in range(self.WT64.shape[0])]
             c = len(Wr)
-            # projections onto the covariates, P[z, a, s, m] = <row_a[s], W_m>; U = W Q W^T is applied through them:
-            # <U A_a, A_b> = sum_s PA[a,s] Q PA[b,s],  <C_a, U blkA_b> = sum_s PC[a,s] Q PblkA[b,s]  (base.py:583-593;
-            # UXXz_b = whole-data UXXz_b - U(block XXz_b), streaming_rhe.py:35-36)
-            PA, PbA = (t.reshape(batch, ne, k, c) for t in self._lin_dots(self._sub_rows(A), Wr, 1, batch))
-            PC = self._lin_dots(self._sub_rows(Cr), Wr, 1, batch)[0].reshape(batch, ne, k, c)
+        acc = lambda old, new: new if old is None else old + new
+        for s0, nc in self.intervals:
+            A = self._loo_rows(tot_A, store, "Z", "eZ", nA, s0, nc)
+            # <XXz_a, XXz_b> of the slot, expanded around the whole-data rows: (t - b)(t - b)^T = tt - bt - (bt)^T + bb.
+            # The whole-data rows are then read once per 64 block rows (matrix-core path) instead of once per block.
+            A_tot = [Row(r.tot) for r in A]
+            A_blk = [None if r.blk is None else Row(None, r.blk, r.mul, r.stride) for r in A]
+            fixed = list(A_tot)
+            if self.genie_model is not None:
+                fixed.append(Row(self.Z64[s0:s0 + nc]))
+            if use_cov:
+                fixed.append(Row(self.UZ64[s0:s0 + nc]))
+            bpart = self._dots(A_blk, fixed, nc, batch)           # block rows evaluate to -blk: -<b_a, fixed>
+            g = self._dots(A_tot, fixed, nc, 1) + bpart
+            gram = acc(gram, g[:, :, :ne] + bpart[:, :, :ne].transpose(1, 2) + self._dots(A_blk, A_blk, nc, batch))
+            col = ne
+            if self.genie_model is not None:
+                tz = acc(tz, g[:, :, col]); col += 1
+            if use_cov:
+                tk = acc(tk, g[:, :, col])
+                Cr = self._loo_rows(tot_C, store, "UZ", "eUZ", nC, s0, nc)
+                Dr = [Row(D_tot[a, s0:s0 + nc]) for a in range(D_tot.shape[0])] + ([Row(nD[s0:s0 + nc])] if nD is not None else [])
+                gCD = acc(gCD, self._lin_dots(Cr, Dr, nc, batch)[0])      # <XXUz_a (LOO), UXXz_b (whole data)>
+                # projections onto the covariates, P[z, a, s, m] = <row_a[s], W_m>; U = W Q W^T is applied through them:
+                # <U A_a, A_b> = sum_s PA[a,s] Q PA[b,s],  <C_a, U blkA_b> = sum_s PC[a,s] Q PblkA[b,s]  (base.py:583-593;
+                # UXXz_b = whole-data UXXz_b - U(block XXz_b), streaming_rhe.py:35-36)
+                pa, pba = (t.reshape(batch, ne, nc, c) for t in self._lin_dots(self._sub_rows(A, nc), Wr, 1, batch))
+                PA_l.append(pa); PbA_l.append(pba)
+                PC_l.append(self._lin_dots(self._sub_rows(Cr, nc), Wr, 1, batch)[0].reshape(batch, ne, nc, c))
+        if use_cov:
+            PA, PbA, PC = (torch.cat(l, dim=2) if len(l) > 1 else l[0] for l in (PA_l, PbA_l, PC_l))
             Q = self.Q64
             flat = lambda P: P.reshape(batch, ne, k * c)
             uaa = flat(PA @ Q) @ flat(PA).transpose(1, 2)

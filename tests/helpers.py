@@ -9,10 +9,10 @@ from oracle import rhe_oracle as O
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 RHE_CASES = ["rhe_1bin_nocov", "rhe_3bin_nocov_rem", "rhe_3bin_cov", "rhe_1bin_missing",
-             "rhe_1bin_missing_mean", "rhe_1bin_n1024", "rhe_2bin_jn1", "rhe_1bin_2traits"]
+             "rhe_1bin_missing_mean", "rhe_1bin_n1024", "rhe_2bin_jn1", "rhe_1bin_2traits", "rhe_2bin_cov_k35"]
 STREAMING_CASES = ["srhe_3bin_cov", "srhe_2bin_missing_cov"]
 DOM_CASES = ["rhe_dom_2bin", "rhe_dom_cov"]
-GENIE_CASES = ["genie_gxe_2bin", "genie_gxe_cov", "genie_gxe_nxe_2bin", "genie_gxe_nxe_cov"]
+GENIE_CASES = ["genie_gxe_2bin", "genie_gxe_cov", "genie_gxe_nxe_2bin", "genie_gxe_nxe_cov", "genie_gxe_k33"]
 RESULT_KEYS_RHE = ["sigma_ests_total", "sig_errs", "h2_total", "h2_errs", "enrichment_total", "enrichment_errs",
                    "h2_total_overlap", "h2_errs_overlap", "enrichment_total_overlap", "enrichment_errs_overlap"]
 RESULT_KEYS_GENIE = RESULT_KEYS_RHE[:6]

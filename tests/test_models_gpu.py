@@ -42,7 +42,8 @@ def _assert_dict(res, z, t, keys, rtol=RTOL):
 
 
 @pytest.mark.parametrize("name", ["rhe_1bin_nocov", "rhe_3bin_nocov_rem", "rhe_3bin_cov", "rhe_1bin_missing",
-                                  "rhe_1bin_missing_mean", "rhe_1bin_n1024", "rhe_2bin_jn1", "rhe_1bin_2traits"])
+                                  "rhe_1bin_missing_mean", "rhe_1bin_n1024", "rhe_2bin_jn1", "rhe_1bin_2traits",
+                                  "rhe_2bin_cov_k35"])
 def test_rhe_matches_reference(name, tmp_path):
     z = load_golden(name)
     m, log = _run_model(z, tmp_path, "RHE")
@@ -107,7 +108,8 @@ def test_f16_mode_close(tmp_path):
     _assert_dict(res, z, 0, ["sigma_ests_total", "h2_total"], rtol=5e-4)
 
 
-@pytest.mark.parametrize("name", ["genie_gxe_2bin", "genie_gxe_nxe_2bin", "genie_gxe_cov", "genie_gxe_nxe_cov"])
+@pytest.mark.parametrize("name", ["genie_gxe_2bin", "genie_gxe_nxe_2bin", "genie_gxe_cov", "genie_gxe_nxe_cov",
+                                  "genie_gxe_k33"])
 def test_genie_matches_reference(name, tmp_path):
     """GENIE G+GxE(+NxE), with and without covariates (two engine passes when the columns exceed one engine).
     The G+GxE goldens include the reference's last-estimate quirk, which makes the system ill-conditioned
