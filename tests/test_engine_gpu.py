@@ -276,3 +276,33 @@ def test_value_coding_recode_roundtrip_and_identical_results(dev):
         eng.close()
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_more_bins_than_one_segment_table(dev):
+    """70 bins in one call: the by-value segment table holds 64, so the call is cut into two chunks; with RHS columns on
+    two tiles.  Against one call per bin."""
+    from pyrhe_amd import engine
+    n, m, k = 3000, 1500, 12
+    rng = np.random.default_rng(17)
+    packed = engine.recode_rows(engine.synth_genotypes(m, n, 5, 0, dev), "value")
+    bins = rng.integers(0, 70, m)
+    lists = [np.nonzero(bins == b)[0].astype(np.int32) for b in range(70)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+    entries = torch.from_numpy(np.concatenate(lists)).to(dev)
+    eng = engine.SketchEngine(n, n, max_entries=m, device=dev)
+    eng.set_coding("value")
+    keep = eng.keep_vector([])
+    Z = torch.zeros((2 * k, eng.n_pad), device=dev)
+    Z[:, :n] = torch.from_numpy(rng.standard_normal((2 * k, n)).astype(np.float32)).to(dev)
+    y = torch.zeros((1, eng.n_pad), device=dev)
+    y[:, :n] = torch.from_numpy(rng.standard_normal((1, n)).astype(np.float32)).to(dev)
+    eng.set_rhs(Z, y, keep)
+    sk, nm, _ = eng.sketch_block(packed, entries, offs)
+    torch.cuda.synchronize()
+    for b in (0, 1, 33, 63, 64, 65, 69):
+        e1 = torch.from_numpy(lists[b]).to(dev)
+        s1, n1, _ = eng.sketch_block(packed, e1, [0, len(lists[b])])
+        torch.cuda.synchronize()
+        assert (sk[b] - s1[0]).abs().max().item() <= 2e-6 * s1.abs().max().item(), b
+        assert torch.allclose(nm[b], n1[0], rtol=1e-6), b
+    eng.close()
