@@ -148,6 +148,11 @@ int pyrhe_engine_block_stats(pyrhe_engine_t* e, const uint8_t* packed, int64_t n
  * streaming pass.  blocks / out: device; n and block_stride multiples of 4.   Asynchronous on `stream`.
  */
 int pyrhe_sum_blocks(const float* blocks, int n_blocks, int64_t block_stride, int64_t n, double* out, void* stream);
+/* out[i] = sum_j weights[j] * blocks[j * block_stride + i] (weights: device float64 [n_blocks]).  With weights jn - j it is
+ * the whole-data UXXz argument of the reference's streaming pass 1, which applies U to the RUNNING sum of XXz
+ * (pyrhe/src/models/rhe/streaming_rhe.py:18-21): sum_j U(sum_{i<=j} XXz_i) = U(sum_i (jn - i) XXz_i).   Asynchronous. */
+int pyrhe_sum_blocks_weighted(const float* blocks, int n_blocks, int64_t block_stride, int64_t n,
+                              const double* weights, double* out, void* stream);
 
 /*
  * Leave-one-out inner products for the normal equations: the Gram loops of Base.setup_lhs_rhs_jackknife

@@ -1624,12 +1624,13 @@ __global__ void add_partials_kernel(float4* __restrict__ out, const float4* __re
 // out[i] = sum_j (double) blocks[j * stride + i]: the float64 "aggregate" over per-block float32 sketches
 // (base_streaming.py:21-32 / base.py:468-471) in one streaming pass, blocks added in order j = 0, 1, ...
 __global__ void sum_blocks_kernel(const float* __restrict__ blocks, int n_blocks, int64_t stride, int64_t n4,
-                                  double* __restrict__ out) {
+                                  double* __restrict__ out, const double* __restrict__ weights) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         for (int j = 0; j < n_blocks; ++j) {
             const float4 v = reinterpret_cast<const float4*>(blocks + (int64_t)j * stride)[i];
-            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+            const double w = weights ? weights[j] : 1.0;
+            a0 += w * (double)v.x; a1 += w * (double)v.y; a2 += w * (double)v.z; a3 += w * (double)v.w;
         }
         double* o = out + 4 * i;
         o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
@@ -2320,7 +2321,17 @@ extern "C" int pyrhe_sum_blocks(const float* blocks, int n_blocks, int64_t block
     if (!blocks || !out) return fail(PYRHE_EINVAL, "NULL argument");
     if (n <= 0 || n % 4 || block_stride % 4) return fail(PYRHE_EINVAL, "n and block_stride must be positive multiples of 4");
     if (n_blocks < 0) return fail(PYRHE_EINVAL, "n_blocks negative");
-    sum_blocks_kernel<<<4096, 256, 0, (hipStream_t)stream_>>>(blocks, n_blocks, block_stride, n / 4, out);
+    sum_blocks_kernel<<<4096, 256, 0, (hipStream_t)stream_>>>(blocks, n_blocks, block_stride, n / 4, out, nullptr);
+    HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
+extern "C" int pyrhe_sum_blocks_weighted(const float* blocks, int n_blocks, int64_t block_stride, int64_t n,
+                                         const double* weights, double* out, void* stream_) {
+    if (!blocks || !out || !weights) return fail(PYRHE_EINVAL, "NULL argument");
+    if (n <= 0 || n % 4 || block_stride % 4) return fail(PYRHE_EINVAL, "n and block_stride must be positive multiples of 4");
+    if (n_blocks < 0) return fail(PYRHE_EINVAL, "n_blocks negative");
+    sum_blocks_kernel<<<4096, 256, 0, (hipStream_t)stream_>>>(blocks, n_blocks, block_stride, n / 4, out, weights);
     HIPCHK(hipGetLastError());
     return PYRHE_OK;
 }

@@ -44,6 +44,7 @@ SYMBOLS = {
     "pyrhe_recode_rows": (_i32, [_vp, _i64, _i64, _i32, _vp]),
     "pyrhe_engine_set_coding": (_i32, [_vp, _i32]),
     "pyrhe_sum_blocks": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
+    "pyrhe_sum_blocks_weighted": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     "pyrhe_engine_loo_dots": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "pyrhe_synth_genotypes": (_i32, [_vp, _i64, _i64, _i64, _u64, _i64, _vp]),
     "pyrhe_engine_info": (_i64, [_vp, _i32]),
@@ -180,17 +181,29 @@ def synth_genotypes(n_rows: int, n_samples: int, seed: int, row0: int, device, o
     return out
 
 
-def sum_blocks(blocks: torch.Tensor) -> torch.Tensor:
-    """``blocks [jl, ...]`` float32 (contiguous) -> float64 sum over the first dimension, by the HIP kernel when the tensor
-    lives on a GPU (``pyrhe_sum_blocks``), by torch on the CPU (multi-process CPU tests of the driver only)."""
+def sum_blocks(blocks: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``blocks [jl, ...]`` float32 (contiguous) -> float64 (weighted) sum over the first dimension, by the HIP kernel when
+    the tensor lives on a GPU (``pyrhe_sum_blocks[_weighted]``), by torch on the CPU (multi-process CPU tests of the
+    driver only).  ``weights``: float64 ``[jl]`` on the same device."""
     if blocks.device.type != "cuda" or blocks.shape[0] == 0 or (blocks[0].numel() % 4):
-        return blocks.sum(dim=0, dtype=torch.float64) if blocks.shape[0] else torch.zeros(blocks.shape[1:], dtype=torch.float64, device=blocks.device)
+        if not blocks.shape[0]:
+            return torch.zeros(blocks.shape[1:], dtype=torch.float64, device=blocks.device)
+        b64 = blocks.to(torch.float64)
+        if weights is not None:
+            b64 = b64 * weights.reshape((-1,) + (1,) * (blocks.dim() - 1))
+        return b64.sum(dim=0)
     assert blocks.dtype == torch.float32 and blocks.is_contiguous()
     out = torch.empty(blocks.shape[1:], dtype=torch.float64, device=blocks.device)
     n = blocks[0].numel()
+    lib = load_library()
     with torch.cuda.device(blocks.device):
-        _check(load_library().pyrhe_sum_blocks(_ptr(blocks), blocks.shape[0], n, n, _ptr(out), _stream_ptr(blocks.device)),
-               "pyrhe_sum_blocks")
+        if weights is None:
+            _check(lib.pyrhe_sum_blocks(_ptr(blocks), blocks.shape[0], n, n, _ptr(out), _stream_ptr(blocks.device)),
+                   "pyrhe_sum_blocks")
+        else:
+            assert weights.dtype == torch.float64 and weights.is_contiguous() and weights.numel() == blocks.shape[0]
+            _check(lib.pyrhe_sum_blocks_weighted(_ptr(blocks), blocks.shape[0], n, n, _ptr(weights), _ptr(out),
+                                                 _stream_ptr(blocks.device)), "pyrhe_sum_blocks_weighted")
     return out
 
 

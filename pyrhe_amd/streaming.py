@@ -443,36 +443,27 @@ class SketchRunner:
         use_cov = self.cov is not None
         q4 = use_cov and self.streaming and self.compat == "reference"
         wsum = None
-        if not q4:
-            # Block sums as ONE float64 reduction over the stored per-block sketches (the reference adds the blocks one
-            # by one in float64, base.py:468-471; any order agrees to 1e-16).  U is linear, so the "fixed" UXXz total is
-            # U applied to the total (float32 rounding order differs from per-block application at the 1e-7 level).
-            tot_sk = [sum_blocks(b) for b in self.blocks_sk]
-            tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
-            tot_skd = tot_nmd = None
-            if self.dom:
-                tot_skd = [sum_blocks(b) for b in self.blocks_skd]
-                tot_nmd = [b[:jl].sum(dim=0) for b in self.blocks_nmd]
-            tot_A, tot_C, tot_r = self._block_estimates(tot_sk, tot_nm, tot_skd, tot_nmd)
-            tot_A, tot_r = tot_A.contiguous(), tot_r.clone()
-            tot_C = tot_C.contiguous() if use_cov else None
-            D_tot = self._apply_U(tot_A, f32=True) if use_cov else None
-        else:
-            tot_A = torch.zeros((ne_g, k, self.n_pad), dtype=f64, device=dev)
-            tot_C = torch.zeros_like(tot_A)
-            tot_r = torch.zeros(ne_g, dtype=f64, device=dev)
-            D_tot = torch.zeros_like(tot_A)
-            wsum = torch.zeros_like(tot_A) if self.world > 1 else None
-            for jl_i in range(jl):
-                A, C, r = self._block_estimates(*self._stored_block(jl_i))
-                tot_A += A
-                tot_r += r
-                tot_C += C
-                if self.world == 1:
-                    # quirk Q4 (streaming_rhe.py:18-21): U applied to the RUNNING sum of XXz, float32
-                    D_tot += self._apply_U(tot_A, f32=True)
-                else:
-                    wsum += A * float(jn - (self.j0 + jl_i))
+        # Block sums as ONE float64 reduction over the stored per-block sketches (the reference adds the blocks one by
+        # one in float64, base.py:468-471; any order agrees to 1e-16).  U is linear, so the "fixed" UXXz total is U
+        # applied to the total (float32 rounding order differs from per-block application at the 1e-7 level).
+        tot_sk = [sum_blocks(b) for b in self.blocks_sk]
+        tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
+        tot_skd = tot_nmd = None
+        if self.dom:
+            tot_skd = [sum_blocks(b) for b in self.blocks_skd]
+            tot_nmd = [b[:jl].sum(dim=0) for b in self.blocks_nmd]
+        tot_A, tot_C, tot_r = self._block_estimates(tot_sk, tot_nm, tot_skd, tot_nmd)
+        tot_A, tot_r = tot_A.contiguous(), tot_r.clone()
+        tot_C = tot_C.contiguous() if use_cov else None
+        if q4:
+            # quirk Q4 (streaming_rhe.py:18-21): the reference applies U to the RUNNING sum of XXz after every block;
+            # U is linear, so sum_j U(sum_{i<=j} XXz_i) = U(sum_i (jn - i) XXz_i): one weighted block sum, one U
+            # (float32 rounding order differs from the block-by-block application at the 1e-7 level)
+            w = torch.arange(jn - self.j0, jn - self.j0 - jl, -1, dtype=f64, device=dev) if jl else torch.zeros(0, dtype=f64, device=dev)
+            w_sk = [sum_blocks(b, w) for b in self.blocks_sk]
+            w_skd = [sum_blocks(b, w) for b in self.blocks_skd] if self.dom else None
+            wsum = self._block_estimates(w_sk, tot_nm, w_skd, tot_nmd)[0].contiguous()
+        D_tot = (self._apply_U(wsum if q4 else tot_A, f32=True) if use_cov else None)
         if self.world > 1:
             # ONE all-reduce per pass: XXz | yXXy (| XXUz | the (jn - j)-weighted XXz of quirk Q4) packed in one buffer
             parts = [tot_A, tot_r] + ([tot_C] if use_cov else []) + ([wsum] if q4 else [])

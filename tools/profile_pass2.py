@@ -18,7 +18,7 @@ if ncov:
     cov = np.concatenate([np.ones((N, 1)), np.random.default_rng(2).normal(size=(N, ncov - 1))], axis=1)
 engine = eng_mod.SketchEngine(N, N, max_entries=plan.max_block, device=dev)
 runner = SketchRunner(engine, geno, plan, (0, jn), n_orig=N, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True,
-                      compat="fixed" if cov is not None else "reference")
+                      compat=os.environ.get("COMPAT", "fixed" if cov is not None else "reference"))
 runner.begin_trait(y, check_missing=False)
 runner.pass1(); torch.cuda.synchronize()
 t0 = time.perf_counter(); runner.pass1(); torch.cuda.synchronize(); print("pass1 s", time.perf_counter() - t0)
