@@ -329,17 +329,20 @@ class SketchRunner:
             self._entries_cache[j] = (torch.from_numpy(cat).to(self.device), offs)
         return self._entries_cache[j]
 
-    def sketch_local_blocks(self, out_sk, out_norm, pass_index: int = 0):
+    def sketch_local_blocks(self, out_sk, out_norm, pass_index: int = 0, after_block=None):
         """Enqueue the sketch of every local block: ``out_sk[p][jl]`` / ``out_norm[p][jl]`` receive the per-block
-        outputs of engine pass p (``[nbin, n_sketch_p, n_pad]`` float32 / ``[nbin, n_norm_p]`` float64)."""
+        outputs of engine pass p (``[nbin, n_sketch_p, n_pad]`` float32 / ``[nbin, n_norm_p]`` float64).  With a
+        one-slot store (``recompute_pass2``) every block lands in slot 0 and ``after_block(jl_index, j)`` consumes it."""
         any_missing = bool(self._check_missing and self._ingest_stats()[1].any())
         draw = self._uniform_stream(pass_index) if any_missing else None
-        pipelined = [eng for eng in self.engs if hasattr(eng, "set_async")]
+        one_slot = after_block is not None
+        pipelined = [] if one_slot else [eng for eng in self.engs if hasattr(eng, "set_async")]
         for eng in pipelined:
             eng.set_async(True)       # blocks write distinct outputs: let GEMM 1 of block j+1 overlap GEMM 2 of block j
         fills = []                    # keep fill tensors alive until the join
         try:
-            for jl, j in enumerate(range(self.j0, self.j1)):
+            for jl_i, j in enumerate(range(self.j0, self.j1)):
+                jl = 0 if one_slot else jl_i
                 ent, offs = self._entries(j)
                 s, e = self.plan.range(j)
                 fill = None
@@ -355,6 +358,8 @@ class SketchRunner:
                     else:
                         self.engs[p].sketch_block(self._block_rows(j), ent, offs, fill=fill, out_sketch=out_sk[p][jl],
                                                   out_norm=out_norm[p][jl], accumulate=False)
+                if one_slot:
+                    after_block(jl_i, j)
         finally:
             for eng in pipelined:
                 eng.join()
@@ -382,6 +387,16 @@ class SketchRunner:
         self._check_missing = check_missing
         self._install_rhs(y)
         dev = self.device
+        # The per-block sketches stay in HBM for pass 2 when they fit (C3: 2 GB, C4: 32 GB of the 288); otherwise pass 2
+        # re-sketches every block like the reference's second pass and only one block's outputs are ever resident.
+        store_bytes = jl * nb * sum(ns for ns, _ in self.pass_shapes) * self.n_pad * 4 * (2 if self.dom else 1)
+        if not self.recompute_pass2 and dev.type == "cuda":
+            free = torch.cuda.mem_get_info(dev)[0]
+            if store_bytes > 0.8 * free:
+                self.recompute_pass2 = True
+                self.timings["recompute_pass2"] = f"auto: {store_bytes / 1e9:.1f} GB of block sketches vs {free / 1e9:.1f} GB free"
+        if self.recompute_pass2:
+            jl = min(jl, 1)
         self.blocks_sk = [torch.empty((jl, nb, ns, self.n_pad), dtype=torch.float32, device=dev) for ns, _ in self.pass_shapes]
         self.blocks_nm = [torch.zeros((max(jl, 1), nb, nn), dtype=torch.float64, device=dev) for _, nn in self.pass_shapes]
         self.blocks_skd = [torch.empty_like(b) for b in self.blocks_sk] if self.dom else None
@@ -437,21 +452,49 @@ class SketchRunner:
         (base_streaming.py:21-58 / base.py:465-500: float64 sums in block order) + the cross-GPU all-reduce."""
         plan, k = self.plan, self.k
         jn, jl, dev = plan.n_jack, self.j1 - self.j0, self.device
-        self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0)
         ne_g = 2 * plan.n_bin if self.dom else plan.n_bin + self.n_gxe
         f64 = torch.float64
         use_cov = self.cov is not None
         q4 = use_cov and self.streaming and self.compat == "reference"
         wsum = None
-        # Block sums as ONE float64 reduction over the stored per-block sketches (the reference adds the blocks one by
-        # one in float64, base.py:468-471; any order agrees to 1e-16).  U is linear, so the "fixed" UXXz total is U
-        # applied to the total (float32 rounding order differs from per-block application at the 1e-7 level).
-        tot_sk = [sum_blocks(b) for b in self.blocks_sk]
-        tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
-        tot_skd = tot_nmd = None
-        if self.dom:
-            tot_skd = [sum_blocks(b) for b in self.blocks_skd]
-            tot_nmd = [b[:jl].sum(dim=0) for b in self.blocks_nmd]
+        w = torch.arange(jn - self.j0, jn - self.j0 - jl, -1, dtype=f64, device=dev) if jl else torch.zeros(0, dtype=f64, device=dev)
+        w_sk = w_skd = None
+        if not self.recompute_pass2:
+            self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0)
+            # Block sums as ONE float64 reduction over the stored per-block sketches (the reference adds the blocks one
+            # by one in float64, base.py:468-471; any order agrees to 1e-16).  U is linear, so the "fixed" UXXz total is
+            # U applied to the total (float32 rounding order differs from per-block application at the 1e-7 level).
+            tot_sk = [sum_blocks(b) for b in self.blocks_sk]
+            tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
+            tot_skd = tot_nmd = None
+            if self.dom:
+                tot_skd = [sum_blocks(b) for b in self.blocks_skd]
+                tot_nmd = [b[:jl].sum(dim=0) for b in self.blocks_nmd]
+            if q4:
+                w_sk = [sum_blocks(b, w) for b in self.blocks_sk]
+                w_skd = [sum_blocks(b, w) for b in self.blocks_skd] if self.dom else None
+        else:
+            # one-slot store: every block is added to the float64 totals (and the (jn - j)-weighted ones of quirk Q4)
+            # right after its sketch, in block order
+            zeros = lambda lst: [torch.zeros(b.shape[1:], dtype=f64, device=dev) for b in lst]
+            tot_sk, tot_nm = zeros(self.blocks_sk), zeros(self.blocks_nm)
+            tot_skd, tot_nmd = (zeros(self.blocks_skd), zeros(self.blocks_nmd)) if self.dom else (None, None)
+            if q4:
+                w_sk = zeros(self.blocks_sk)
+                w_skd = zeros(self.blocks_skd) if self.dom else None
+
+            def add(jl_i, j):
+                for p_ in range(self.n_pass):
+                    tot_sk[p_] += self.blocks_sk[p_][0]
+                    tot_nm[p_] += self.blocks_nm[p_][0]
+                    if self.dom:
+                        tot_skd[p_] += self.blocks_skd[p_][0]
+                        tot_nmd[p_] += self.blocks_nmd[p_][0]
+                    if q4:
+                        w_sk[p_].add_(self.blocks_sk[p_][0], alpha=float(jn - j))
+                        if self.dom:
+                            w_skd[p_].add_(self.blocks_skd[p_][0], alpha=float(jn - j))
+            self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0, after_block=add)
         tot_A, tot_C, tot_r = self._block_estimates(tot_sk, tot_nm, tot_skd, tot_nmd)
         tot_A, tot_r = tot_A.contiguous(), tot_r.clone()
         tot_C = tot_C.contiguous() if use_cov else None
@@ -459,9 +502,6 @@ class SketchRunner:
             # quirk Q4 (streaming_rhe.py:18-21): the reference applies U to the RUNNING sum of XXz after every block;
             # U is linear, so sum_j U(sum_{i<=j} XXz_i) = U(sum_i (jn - i) XXz_i): one weighted block sum, one U
             # (float32 rounding order differs from the block-by-block application at the 1e-7 level)
-            w = torch.arange(jn - self.j0, jn - self.j0 - jl, -1, dtype=f64, device=dev) if jl else torch.zeros(0, dtype=f64, device=dev)
-            w_sk = [sum_blocks(b, w) for b in self.blocks_sk]
-            w_skd = [sum_blocks(b, w) for b in self.blocks_skd] if self.dom else None
             wsum = self._block_estimates(w_sk, tot_nm, w_skd, tot_nmd)[0].contiguous()
         D_tot = (self._apply_U(wsum if q4 else tot_A, f32=True) if use_cov else None)
         if self.world > 1:

@@ -191,3 +191,35 @@ def test_full_sample_count_value_coding_segments_and_dots():
         ref_s = (sk[z].double() ** 2).sum().item()
         assert abs(got_self[z, 0, 0].item() - ref_s) <= 1e-11 * abs(ref_s) + 1e-6
     eng.close()
+
+
+def test_store_falls_back_to_one_slot_when_hbm_is_short(monkeypatch):
+    """When the per-block sketch store would not fit the free HBM the runner keeps one block slot, accumulates the float64
+    totals block by block and re-sketches in pass 2: same systems as the stored mode (incl. the weighted UXXz of Q4)."""
+    from pyrhe_amd import engine
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner
+    dev = torch.device("cuda", 0)
+    n, m, jn, k = 4000, 800, 8, 10
+    geno = engine.recode_rows(engine.synth_genotypes(m, n, SEED, 21, dev), "value")
+    rng = np.random.default_rng(4)
+    annot = np.zeros((m, 2), np.int64)
+    annot[np.arange(m), rng.integers(0, 2, m)] = 1
+    plan = BlockPlan(annot, jn)
+    np.random.seed(0)
+    Z = np.random.randn(n, k)
+    y = rng.normal(size=n); y -= y.mean()
+    cov = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, 2))], axis=1)
+    out = []
+    for short in (False, True):
+        eng = engine.SketchEngine(n, n, plan.max_block, device=dev)
+        eng.set_coding("value")
+        runner = SketchRunner(eng, geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True,
+                              compat="reference")
+        if short:
+            monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (1 << 20, 1 << 38))
+        sysm = runner.run_trait(y, check_missing=False)
+        assert runner.recompute_pass2 == short
+        assert runner.blocks_sk[0].shape[0] == (1 if short else jn)
+        out.append(sysm)
+        eng.close()
+    assert np.allclose(out[0].T, out[1].T, rtol=1e-9) and np.allclose(out[0].q, out[1].q, rtol=1e-12)
