@@ -81,6 +81,11 @@ def h2_overlapping(sigma_jack: np.ndarray, sigma_total: np.ndarray, n_est: int, 
     reference's own index arithmetic (base.py:382-393), which for the total row j = jn masks
     [jn*step, jn*step + step + M%jn) -- i.e. the trailing M%jn SNPs -- and nothing when M%jn == 0."""
     step, rem = n_snp // n_jack, n_snp % n_jack
+    # The reference walks every SNP of every bin in Python (M x bins x (jn+1) iterations).  Same sums through the
+    # co-membership counts C[e, b] = #{SNPs in bins e and b}: row e of the definition is sum_b C_j[e, b] sigma_b / M[j][b]
+    # with C_j counted outside the masked range of row j -- exact integers, O(M nb^2) once plus O(step nb^2) per row.
+    member = (np.asarray(annot)[:, :n_est] == 1).astype(np.int64)
+    C_all = member.T @ member
     rows = []
     for j, s in enumerate(_stack(sigma_jack, sigma_total)):
         g = 0
@@ -88,19 +93,10 @@ def h2_overlapping(sigma_jack: np.ndarray, sigma_total: np.ndarray, n_est: int, 
             g += s[e]
         denom = g + s[-1]
         chunk = step if j < n_jack - 1 else step + rem
-        mask = np.ones(n_snp, dtype=bool)
-        mask[j * step: j * step + chunk] = False
-        sub = annot[mask]
-        per_bin = [s[b] / M[j][b] if M[j][b] != 0 else 0 for b in range(n_est)]
-        row = []
-        for e in range(n_est):
-            acc = 0
-            for snp in np.where(sub[:, e] == 1)[0]:
-                inner = 0
-                for b in np.where(sub[snp, :] == 1)[0].tolist():
-                    inner += per_bin[b]
-                acc += inner
-            row.append(acc / denom)
+        cut = member[j * step: j * step + chunk]                  # NumPy slicing clips at n_snp like the reference's mask
+        C = C_all - cut.T @ cut
+        per_bin = np.array([s[b] / M[j][b] if M[j][b] != 0 else 0 for b in range(n_est)], dtype=np.float64)
+        row = list((C @ per_bin) / denom)
         row.append(g / denom)
         rows.append(row)
     rows = np.array(rows)
