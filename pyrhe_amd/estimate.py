@@ -84,7 +84,7 @@ def h2_overlapping(sigma_jack: np.ndarray, sigma_total: np.ndarray, n_est: int, 
     # The reference walks every SNP of every bin in Python (M x bins x (jn+1) iterations).  Same sums through the
     # co-membership counts C[e, b] = #{SNPs in bins e and b}: row e of the definition is sum_b C_j[e, b] sigma_b / M[j][b]
     # with C_j counted outside the masked range of row j -- exact integers, O(M nb^2) once plus O(step nb^2) per row.
-    member = (np.asarray(annot)[:, :n_est] == 1).astype(np.int64)
+    member = (np.asarray(annot)[:, :n_est] == 1).astype(np.float64)      # counts < 2^53: exact in float64, and BLAS-fast
     C_all = member.T @ member
     rows = []
     for j, s in enumerate(_stack(sigma_jack, sigma_total)):
