@@ -70,6 +70,10 @@ def _import_reference():
     from pyrhe.src.models.genie import GENIE
     from pyrhe.src.models.rhe_dom import RHE_DOM
     from pyrhe.src.util.logger import Logger
+    import pyrhe.src.models.genie.streaming_genie as sg
+    import pyrhe.src.models.rhe_dom.streaming_rhe_dom as sd
+    global _STREAMING_EXTRA
+    _STREAMING_EXTRA = {"StreamingGENIE": sg.StreamingGENIE, "StreamingRHE_DOM": sd.StreamingRHE_DOM}
     return RHE, StreamingRHE, GENIE, Logger, RHE_DOM
 
 
@@ -91,6 +95,10 @@ CASES = [
          kw=dict(num_jack=10, num_random_vec=35, seed=14)),
     dict(name="genie_gxe_k33", cohort=dict(n_indv=403, n_snp=240, seed=27, nbin=1, with_env=True), model="GENIE",
          kw=dict(num_jack=10, num_random_vec=33, seed=15, genie_model="G+GxE+NxE")),
+    dict(name="sgenie_gxe_nxe_cov", cohort=dict(n_indv=403, n_snp=240, seed=28, nbin=2, with_env=True, with_cov=3), model="StreamingGENIE",
+         kw=dict(num_jack=10, num_random_vec=10, seed=16, genie_model="G+GxE+NxE")),
+    dict(name="srhe_dom_cov", cohort=dict(n_indv=403, n_snp=240, seed=29, nbin=2, with_cov=3), model="StreamingRHE_DOM",
+         kw=dict(num_jack=10, num_random_vec=10, seed=17)),
     dict(name="rhe_1bin_missing", cohort=dict(n_indv=403, n_snp=240, seed=14, missing_geno=0.02, missing_pheno=5),
          model="RHE", kw=dict(num_jack=10, num_random_vec=10, seed=3)),
     dict(name="rhe_1bin_missing_mean", cohort=dict(n_indv=403, n_snp=240, seed=14, missing_geno=0.02, missing_pheno=5),
@@ -127,8 +135,14 @@ def run_case(case, classes):
         log = Logger(output_file=None, suppress=True, debug_mode=False)
         params = dict(model="rhe", geno_file=paths["geno"], annot_file=paths["annot"], pheno_file=paths["pheno"],
                       cov_file=paths.get("cov"), device="cpu", log=log, **{k: v for k, v in kw.items() if k != "genie_model"})
-        streaming = case["model"] == "StreamingRHE"
-        if streaming:
+        streaming = case["model"].startswith("Streaming")
+        if case["model"] == "StreamingGENIE":
+            params.update(multiprocessing=True, num_workers=1, env_file=paths["env"], genie_model=kw["genie_model"], model="genie")
+            cls = _STREAMING_EXTRA["StreamingGENIE"]
+        elif case["model"] == "StreamingRHE_DOM":
+            params.update(multiprocessing=True, num_workers=1, model="rhe_dom")
+            cls = _STREAMING_EXTRA["StreamingRHE_DOM"]
+        elif streaming:
             params.update(multiprocessing=True, num_workers=1)
             cls = StreamingRHE
         elif case["model"] == "GENIE":

@@ -315,7 +315,9 @@ def precompute(p: Problem, streaming_compat: bool = False) -> State:
         st.M[j] = st.M[jn] - blk.m                      # rhe.py:16 / streaming_rhe.py:16
     n_env = 1 if p.genie_model is not None else 0       # GENIE sets num_env = 1 for every genie_model (genie.py:18)
     for e in range(ne):
-        if not streaming_compat and e >= ne - n_env:
+        # streaming: aggregate skips the last num_env estimates and then fills the N x E slots from the same closed form
+        # (base_streaming.py:24-58); only "G+GxE+NxE" reaches that code without an IndexError
+        if e >= ne - n_env and (not streaming_compat or p.genie_model == "G+GxE+NxE"):
             # Reference quirk (base.py:467,472-481): the LAST estimate of a GENIE model is always treated
             # as "hetero noise", also for "G"/"G+GxE": its total slot is the N x E sketch diag(env)^2 z
             # (closed form of elem_mul(eye(N), env)), not the sum over blocks.

@@ -33,7 +33,7 @@ def oracle_problem(z, trait=0):
                   n_jack=int(z["param_num_jack"]), k=int(z["param_num_random_vec"]), seed=int(z["param_seed"]),
                   missing_indv=miss, cov=cov,
                   impute=str(z["param_geno_impute_method"]) if "param_geno_impute_method" in z else "binary")
-    if str(z["param_model"]) == "RHE_DOM":
+    if str(z["param_model"]) in ("RHE_DOM", "StreamingRHE_DOM"):
         p.dom = True
     if "param_genie_model" in z:
         p.genie_model = str(z["param_genie_model"])

@@ -187,3 +187,37 @@ def test_rhe_dom_matches_reference(name, precision, tmp_path):
     got_lines = "".join(log.msgs[n0:]).splitlines()
     strip = lambda ls: [re.sub(r"-?\d+\.\d+(e-?\d+)?|nan", "#", l) for l in ls]
     assert strip(got_lines) == strip(ref_lines)
+
+
+def test_streaming_genie_matches_reference(tmp_path):
+    """StreamingGENIE("G+GxE+NxE") + covariates against the reference's one-worker streaming run (pass-1 / pass-2 bodies
+    of streaming_genie.py, N x E from the streaming aggregate, running-sum UXXz)."""
+    from tests.helpers import RESULT_KEYS_GENIE
+    z = load_golden("sgenie_gxe_nxe_cov")
+    c = fixtures.cohort_from_npz(z)
+    paths = fixtures.write_cohort_files(c, str(tmp_path))
+    m, log = _run_model(z, tmp_path, "StreamingGENIE", env_file=paths["env"], genie_model="G+GxE+NxE")
+    n0 = len(log.msgs)
+    res = m(trait=0)
+    assert np.array_equal(m.M, z["ref_t0_M"])
+    assert np.abs(m.sigma_est_jackknife - z["ref_t0_sigma_jack"]).max() <= 5e-5 * np.abs(z["ref_t0_sigma_jack"]).max()
+    for k in RESULT_KEYS_GENIE:
+        r = z["ref_t0_res_" + k]
+        assert np.abs(np.asarray(res[k], float) - r).max() <= 5e-5 * max(np.abs(r).max(), 1e-3), k
+    strip = lambda ls: [re.sub(r"-?\d+\.\d+(e-?\d+)?|nan", "#", l) for l in ls]
+    assert strip("".join(log.msgs[n0:]).splitlines()) == strip(str(z["ref_t0_log"]).splitlines())
+
+
+def test_streaming_rhe_dom_matches_reference(tmp_path):
+    """StreamingRHE_DOM + covariates against the reference's one-worker streaming run (streaming_rhe_dom.py)."""
+    from tests.helpers import RESULT_KEYS_GENIE
+    z = load_golden("srhe_dom_cov")
+    m, log = _run_model(z, tmp_path, "StreamingRHE_DOM")
+    n0 = len(log.msgs)
+    res = m(trait=0)
+    assert np.array_equal(m.M, z["ref_t0_M"])
+    for k in RESULT_KEYS_GENIE:
+        r = z["ref_t0_res_" + k]
+        assert np.abs(np.asarray(res[k], float) - r).max() <= 1e-5 * max(np.abs(r).max(), 1e-3), k
+    strip = lambda ls: [re.sub(r"-?\d+\.\d+(e-?\d+)?|nan", "#", l) for l in ls]
+    assert strip("".join(log.msgs[n0:]).splitlines()) == strip(str(z["ref_t0_log"]).splitlines())

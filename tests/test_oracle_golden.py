@@ -95,3 +95,29 @@ def test_block_range_matches_reference_rule():
     # base.py:362-371: last block takes the remainder
     assert [O.block_range(j, 247, 10) for j in (0, 8, 9)] == [(0, 24), (192, 216), (216, 247)]
     assert O.distribute_work(100, 8) == [(0, 13), (13, 26), (26, 39), (39, 52), (52, 65), (65, 78), (78, 91), (91, 100)]
+
+
+def test_streaming_genie_gxe_nxe_cov():
+    """StreamingGENIE("G+GxE+NxE") + covariates, one worker: pass-1 / pass-2 bodies of streaming_genie.py:17-89, the
+    N x E slots filled by the streaming aggregate (base_streaming.py:45-58), running-sum UXXz (Q4)."""
+    z = load_golden("sgenie_gxe_nxe_cov")
+    p, _ = oracle_problem(z)
+    st = O.precompute(p, streaming_compat=True)
+    assert np.array_equal(st.M, z["ref_t0_M"])
+    r = O.genie_results(p, st)
+    assert close(r["sigma_jack"], z["ref_t0_sigma_jack"])
+    for k in RESULT_KEYS_GENIE:
+        assert close(r[k], z["ref_t0_res_" + k]), k
+
+
+def test_streaming_rhe_dom_cov():
+    """StreamingRHE_DOM + covariates, one worker (streaming_rhe_dom.py:9-68)."""
+    z = load_golden("srhe_dom_cov")
+    p, _ = oracle_problem(z)
+    st = O.precompute(p, streaming_compat=True)
+    assert np.array_equal(st.M, z["ref_t0_M"])
+    r = O.rhe_dom_results(p, st)
+    assert close(r["sigma_jack"], z["ref_t0_sigma_jack"])
+    for k in [k[len("ref_t0_res_"):] for k in z.files if k.startswith("ref_t0_res_")]:
+        if k in r:
+            assert close(r[k], z["ref_t0_res_" + k]), k
