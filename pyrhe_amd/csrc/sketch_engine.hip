@@ -591,21 +591,63 @@ __device__ __forceinline__ int seg_of_kb(const SegTab& t, int kb) {
     return g;
 }
 
+// Ordered per-segment sum of the squares written by mid 1 / mid (dominance): WORKGROUP w = (segment g, norm column i)
+// adds vsq[e][i] over the segment's entries -- thread-strided (4 loads in flight per thread), a fixed butterfly per
+// wave, the four wave sums in a fixed order -- and hands the sum to the caller's [nbin][n_norm] array (row tab.bin[g],
+// overwrite or add per tab.acc[g]).  Same bits on every run.  Call with all 256 threads of the workgroup.
+__device__ __forceinline__ void norm_reduce(int wg, const double* __restrict__ vsq, int n_norm, const SegTab& tab,
+                                            double* __restrict__ norm_dst, double* s_part /* shared [4] */) {
+    if (wg >= tab.nseg * n_norm) return;                       // uniform per workgroup
+    const int g = wg / n_norm, i = wg - g * n_norm;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int e1 = tab.start[g + 1];
+    int e = tab.start[g] + threadIdx.x;
+    for (; e + 768 < e1; e += 1024) {
+        s0 += vsq[(int64_t)e * n_norm + i];
+        s1 += vsq[(int64_t)(e + 256) * n_norm + i];
+        s2 += vsq[(int64_t)(e + 512) * n_norm + i];
+        s3 += vsq[(int64_t)(e + 768) * n_norm + i];
+    }
+    for (; e < e1; e += 256) s0 += vsq[(int64_t)e * n_norm + i];
+    double s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        int lo = __double2loint(s), hi = __double2hiint(s);
+        lo = __shfl_xor(lo, off);
+        hi = __shfl_xor(hi, off);
+        s += __hiloint2double(hi, lo);
+    }
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        double* d = norm_dst + (int64_t)tab.bin[g] * n_norm + i;
+        *d = tab.acc[g] ? *d + tot : tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void norm_reduce_kernel(const double* __restrict__ vsq, int n_norm, double* __restrict__ norm_dst,
+                                                          const SegTab tab) {
+    __shared__ double s_part[4];
+    norm_reduce(blockIdx.x, vsq, n_norm, tab, norm_dst, s_part);
+}
+
 // ------------------------------------------------------------------------------------------------
-// mid 1: per entry statistics, V = X^T R, norm accumulation, W = D V (float32) + column maxima
+// mid 1: per entry statistics, V = X^T R, norm squares, W = D V (float32) + column maxima
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mid1_kernel(const float* __restrict__ P, float pscale, int i8, int n_entries, int ncol_p,
                                                    int n_sketch, int n_norm, const float* __restrict__ scale,
                                                    const double* __restrict__ csum, float n_keep, float* __restrict__ mu_out,
                                                    float* __restrict__ Wtmp, uint32_t* __restrict__ wmax_bits,
-                                                   double* __restrict__ norm_acc, int32_t* __restrict__ colsum_out,
+                                                   double* __restrict__ vsq, int32_t* __restrict__ colsum_out,
                                                    const SegTab tab) {
     // workgroup = 64 entries; thread (c16, el): column c16 of a 16-column tile, entries el, el+16, el+32, el+48.
-    // Consecutive lanes read consecutive columns of one entry (coalesced); column maxima / norm sums are kept in
-    // registers over the 4 entries, folded over the wave by 2 shuffles and over the 4 waves through LDS.
+    // Consecutive lanes read consecutive columns of one entry (coalesced); column maxima are kept in registers over
+    // the 4 entries, folded over the wave by 2 shuffles and over the 4 waves through LDS.  Norm columns: the squares
+    // V^2 go to vsq[entry][norm column]; norm_reduce() adds them per segment in a FIXED order (no float64 atomics:
+    // yXXy is reproducible bit for bit).
     __shared__ float s_mu[64], s_d[64];
     __shared__ float s_max[4][16];
-    __shared__ double s_nrm[4][16];
     const int c16 = threadIdx.x & 15, el = threadIdx.x >> 4, wave = threadIdx.x >> 6;
     const int ones = n_sketch + n_norm;
     const int ebase = blockIdx.x * 64;
@@ -614,7 +656,6 @@ __global__ __launch_bounds__(256) void mid1_kernel(const float* __restrict__ P, 
     const int g0 = seg_of_entry(tab, ebase);
     const bool mixed = seg_of_entry(tab, min(ebase + 63, n_entries - 1)) != g0;
     wmax_bits += g0 * kSegCols;
-    norm_acc += g0 * kSegCols;
     if (threadIdx.x < 64) {
         const int e = ebase + threadIdx.x;
         float mu = 0.f, d = 0.f;
@@ -636,7 +677,6 @@ __global__ __launch_bounds__(256) void mid1_kernel(const float* __restrict__ P, 
         const int c = tile * 16 + c16;
         const bool colok = c < ones;
         float mx = 0.f;
-        double s2 = 0.0;
         if (colok) {
             const double inv_s = 1.0 / (double)scale[c];
             const double cs = csum[c] * inv_s;
@@ -659,28 +699,18 @@ __global__ __launch_bounds__(256) void mid1_kernel(const float* __restrict__ P, 
                         if (mixed) atomicMax(&wmax_bits[(seg_of_entry(tab, e) - g0) * kSegCols + c], __float_as_uint(fabsf(w)));
                         else mx = fmaxf(mx, fabsf(w));
                     } else {
-                        if (mixed) atomicAdd(&norm_acc[(seg_of_entry(tab, e) - g0) * kSegCols + c - n_sketch], (double)v * (double)v);
-                        else s2 += (double)v * (double)v;
+                        vsq[(int64_t)e * n_norm + (c - n_sketch)] = (double)v * (double)v;
                     }
                 }
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        s2 += __shfl_xor(s2, 16);
-        s2 += __shfl_xor(s2, 32);
-        if ((threadIdx.x & 63) < 16) {
-            s_max[wave][c16] = mx;
-            s_nrm[wave][c16] = s2;
-        }
+        if ((threadIdx.x & 63) < 16) s_max[wave][c16] = mx;
         __syncthreads();
-        if (threadIdx.x < 16 && colok) {
-            if (c < n_sketch) {
-                const float m = fmaxf(fmaxf(s_max[0][c16], s_max[1][c16]), fmaxf(s_max[2][c16], s_max[3][c16]));
-                atomicMax(&wmax_bits[c], __float_as_uint(m));
-            } else {
-                atomicAdd(&norm_acc[c - n_sketch], s_nrm[0][c16] + s_nrm[1][c16] + s_nrm[2][c16] + s_nrm[3][c16]);
-            }
+        if (threadIdx.x < 16 && colok && c < n_sketch) {
+            const float m = fmaxf(fmaxf(s_max[0][c16], s_max[1][c16]), fmaxf(s_max[2][c16], s_max[3][c16]));
+            atomicMax(&wmax_bits[c], __float_as_uint(m));        // a maximum: order-independent
         }
         __syncthreads();
     }
@@ -699,7 +729,7 @@ __global__ void mid_dom1_kernel(const float* __restrict__ PG, const float* __res
                                 int n_entries, int ncol_p, int n_sketch, int n_norm, const float* __restrict__ scale,
                                 const double* __restrict__ csum, float n_keep, float* __restrict__ cmu,
                                 float* __restrict__ W1, float* __restrict__ W2, uint32_t* __restrict__ wmax1,
-                                uint32_t* __restrict__ wmax2, double* __restrict__ norm_acc) {
+                                uint32_t* __restrict__ wmax2, double* __restrict__ vsq) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int ones = n_sketch + n_norm;
     const bool live = e < n_entries;
@@ -745,10 +775,8 @@ __global__ void mid_dom1_kernel(const float* __restrict__ PG, const float* __res
                 atomicMax(&wmax1[c], __float_as_uint(m1));
                 atomicMax(&wmax2[c], __float_as_uint(m2));
             }
-        } else {
-            double s2 = live ? (double)v * (double)v : 0.0;
-            for (int off = 32; off; off >>= 1) s2 += __shfl_xor(s2, off);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&norm_acc[c - n_sketch], s2);
+        } else if (live) {
+            vsq[(int64_t)e * n_norm + (c - n_sketch)] = (double)v * (double)v;
         }
     }
 }
@@ -766,7 +794,7 @@ __global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restr
                             int n_sketch, int nto, const uint32_t* __restrict__ wmax_bits,
                             half8* __restrict__ wfrag, double* __restrict__ corr, float* __restrict__ wscale,
                             const int32_t* __restrict__ rows, int32_t* __restrict__ rows32,
-                            const double* __restrict__ norm_src, double* __restrict__ norm_dst, int n_norm,
+                            const double* __restrict__ vsq, double* __restrict__ norm_dst, int n_norm,
                             const SegTab tab) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n_kb = tab.kb0[tab.nseg];
@@ -775,12 +803,8 @@ __global__ void mid2_kernel(const float* __restrict__ Wtmp, const float* __restr
         const int idx = (int)gid - tab.kb0[g] * 32;
         rows32[gid] = rows[tab.start[g] + (idx < tab.start[g + 1] - tab.start[g] ? idx : 0)];
     }
-    if (norm_dst && gid < (int64_t)tab.nseg * n_norm) {
-        const int g = (int)gid / n_norm, i = (int)gid % n_norm;
-        double* d = norm_dst + (int64_t)tab.bin[g] * n_norm + i;
-        const double v = norm_src[g * kSegCols + i];
-        *d = tab.acc[g] ? *d + v : v;
-    }
+    __shared__ double s_part[4];
+    if (norm_dst) norm_reduce(blockIdx.x, vsq, n_norm, tab, norm_dst, s_part);
     const int lane = gid & 63;
     int64_t rest = gid >> 6;
     const int tile = rest % nto;
@@ -1326,13 +1350,13 @@ struct pyrhe_engine {
     uint32_t* colmax = nullptr;   // [16*ntl_max]
     uint32_t* keepmask = nullptr; // [n_pad/16]
     float* keep = nullptr;        // [n_pad] private copy
-    // per sub-block workspace (one zeroed region first: P | wmax | corr | normacc)
+    // per sub-block workspace (one zeroed region first: P | wmax | corr)
     uint8_t* ws = nullptr;
     size_t ws_bytes = 0, zero_bytes = 0;
     float* P = nullptr;
     uint32_t* wmax = nullptr;
     double* corr = nullptr;
-    double* normacc = nullptr;
+    double* vsq = nullptr;        // [sub_snps][n_norm] squares of the norm columns, summed per segment by norm_reduce()
     float* mu = nullptr;
     float* Wtmp = nullptr;
     float* wscale = nullptr;
@@ -1346,15 +1370,15 @@ struct pyrhe_engine {
     // sub-block g runs on stream B -- a DRAM-pattern-bound kernel beside an instruction-bound one.  The members
     // above alias the set in use (kernel arguments are captured by value at launch).
     struct WorkSet {
-        uint8_t* base; float* P; uint32_t* wmax; double* corr; double* normacc; float* mu; float* Wtmp; float* wscale;
+        uint8_t* base; float* P; uint32_t* wmax; double* corr; double* vsq; float* mu; float* Wtmp; float* wscale;
         half8* wfrag; int32_t* rows32;
     } sets[2];
-    // dominance (RHE_DOM) extras, allocated on first use: one zeroed region (P2 | wmax2 | normacc2) + W2, cmu, zeros
+    // dominance (RHE_DOM) extras, allocated on first use: one zeroed region (P2 | wmax2) + vsq2, W2, cmu, zeros
     uint8_t* dom_ws = nullptr;
     size_t dom_zero_bytes = 0;
     float *P2 = nullptr, *Wtmp2 = nullptr, *cmu = nullptr, *zcoef = nullptr;
     uint32_t* wmax2 = nullptr;
-    double* normacc2 = nullptr;
+    double* vsq2 = nullptr;
     hipStream_t sA = nullptr, sB = nullptr;
     hipEvent_t evIn = nullptr, evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, evDoneA = nullptr, evDoneB = nullptr;
     uint64_t sub_counter = 0;     // sub-blocks enqueued so far (set = counter & 1)
@@ -1363,7 +1387,7 @@ struct pyrhe_engine {
     bool pending = false;         // work enqueued on the internal streams that the caller's stream has not joined yet
     void use_set(int i) {
         const WorkSet& w = sets[i];
-        ws = w.base; P = w.P; wmax = w.wmax; corr = w.corr; normacc = w.normacc; mu = w.mu; Wtmp = w.Wtmp;
+        ws = w.base; P = w.P; wmax = w.wmax; corr = w.corr; vsq = w.vsq; mu = w.mu; Wtmp = w.Wtmp;
         wscale = w.wscale; wfrag = w.wfrag; rows32 = w.rows32;
     }
     // profiling
@@ -1437,8 +1461,8 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     static_assert(kSegCols == 16 * kMaxTiles, "segment slots hold one value per logical column");
     const size_t oWmax = carve((size_t)kMaxSeg * kSegCols * sizeof(uint32_t));
     const size_t oCorr = carve((size_t)kMaxSeg * kSegCols * sizeof(double));
-    const size_t oNorm = carve((size_t)kMaxSeg * kSegCols * sizeof(double));
     e->zero_bytes = off;
+    const size_t oVsq = carve(S * PYRHE_MAX_COLS * sizeof(double));
     const size_t oMu = carve(S * sizeof(float));
     const size_t oWtmp = carve(S * ncolmax * sizeof(float));
     const size_t oWscale = carve((size_t)kMaxSeg * kSegCols * sizeof(float));
@@ -1455,7 +1479,7 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
         w.P = (float*)(base + oP);
         w.wmax = (uint32_t*)(base + oWmax);
         w.corr = (double*)(base + oCorr);
-        w.normacc = (double*)(base + oNorm);
+        w.vsq = (double*)(base + oVsq);
         w.mu = (float*)(base + oMu);
         w.Wtmp = (float*)(base + oWtmp);
         w.wscale = (float*)(base + oWscale);
@@ -1907,10 +1931,6 @@ __global__ void blk_self_gram_reduce_kernel(const double* __restrict__ partial, 
     out[gid] = s;
 }
 
-__global__ void add_norm_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, int accumulate) {
-    const int i = threadIdx.x;
-    if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
-}
 
 // One implementation behind pyrhe_engine_sketch_block (additive sketches) and pyrhe_engine_sketch_block_dom
 // (additive + dominance sketches, RHE_DOM).
@@ -1970,8 +1990,8 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
         const size_t oP2 = carve(S * nc * sizeof(float) * (e->i8 ? 3 : 1));
         const size_t oWm = carve(nc * sizeof(uint32_t));
-        const size_t oNa = carve(nc * sizeof(double));
         e->dom_zero_bytes = off;
+        const size_t oNa = carve(S * PYRHE_MAX_COLS * sizeof(double));
         const size_t oW2 = carve(S * nc * sizeof(float));
         const size_t oCm = carve(S * sizeof(float));
         const size_t oZc = carve(S * sizeof(float));
@@ -1979,7 +1999,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         HIPCHK(hipMemset(e->dom_ws, 0, off));
         e->P2 = (float*)(e->dom_ws + oP2);
         e->wmax2 = (uint32_t*)(e->dom_ws + oWm);
-        e->normacc2 = (double*)(e->dom_ws + oNa);
+        e->vsq2 = (double*)(e->dom_ws + oNa);
         e->Wtmp2 = (float*)(e->dom_ws + oW2);
         e->cmu = (float*)(e->dom_ws + oCm);
         e->zcoef = (float*)(e->dom_ws + oZc);
@@ -2035,12 +2055,12 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         {
             ProfScope ps(e, stream, 1);
             const int64_t threads = (int64_t)n_kb * e->parts * e->nto * 64;
-            const unsigned grid = (unsigned)((threads + 255) / 256);
+            const unsigned grid = (unsigned)std::max<int64_t>((threads + 255) / 256, (int64_t)tab.nseg * e->n_norm);
             if (g2i8) {
                 const int64_t th = (int64_t)n_kb * 3 * 64;
                 mid2_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, wmaxp, (int4v*)e->wfrag, e->corr, e->wscale);
                 pad_rows_kernel<<<(n_kb * 64 + 255) / 256, 256, 0, stream>>>(rows, n, n_kb * 64, e->rows32);
-                if (ndst) add_norm_kernel<<<1, 64, 0, stream>>>(nsrc, ndst, e->n_norm, acc_now);
+                if (ndst) norm_reduce_kernel<<<tab.nseg * e->n_norm, 256, 0, stream>>>(nsrc, e->n_norm, ndst, tab);
             } else if (e->parts == 2) mid2_kernel<2><<<grid, 256, 0, stream>>>(Wsrc, coef, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale, rows, e->rows32, nsrc, ndst, e->n_norm, tab);
             else mid2_kernel<1><<<grid, 256, 0, stream>>>(Wsrc, coef, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale, rows, e->rows32, nsrc, ndst, e->n_norm, tab);
         }
@@ -2154,16 +2174,16 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             {
                 ProfScope ps(e, stream, 1);
                 mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
-                                                                 (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->normacc,
+                                                                 (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->vsq,
                                                                  out_colsum ? out_colsum + chunk0 : nullptr, tab);
             }
             if (e->n_sketch) {
-                const int rc = run_gemm2(0, e->Wtmp, e->mu, e->wmax, n, kb, out_sketch, false, set, rows, e->n_norm ? e->normacc : nullptr,
+                const int rc = run_gemm2(0, e->Wtmp, e->mu, e->wmax, n, kb, out_sketch, false, set, rows, e->n_norm ? e->vsq : nullptr,
                                          e->n_norm ? out_norm : nullptr, tab, true);
                 if (rc) return rc;
             } else {
-                for (int g = 0; g < tab.nseg && e->n_norm; ++g)
-                    add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc + g * kSegCols, out_norm + (int64_t)tab.bin[g] * e->n_norm, e->n_norm, tab.acc[g]);
+                if (e->n_norm)
+                    norm_reduce_kernel<<<tab.nseg * e->n_norm, 256, 0, stream>>>(e->vsq, e->n_norm, out_norm, tab);
                 if (piped) {
                     HIPCHK(hipEventRecord(e->evA[set], e->sA));
                     HIPCHK(hipStreamWaitEvent(sB2, e->evA[set], 0));
@@ -2208,16 +2228,16 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             {
                 ProfScope ps(e, stream, 1);
                 mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
-                                                                 (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->normacc,
+                                                                 (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->vsq,
                                                                  out_colsum ? out_colsum + offsets_host[b] + s0 : nullptr, tab);
-                if (e->n_norm && !e->n_sketch) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc, normb, e->n_norm, acc_now);
+                if (e->n_norm && !e->n_sketch) norm_reduce_kernel<<<e->n_norm, 256, 0, stream>>>(e->vsq, e->n_norm, normb, tab);
             }
             if (!e->n_sketch && piped) {
                 HIPCHK(hipEventRecord(e->evA[set], e->sA));
                 HIPCHK(hipStreamWaitEvent(sB2, e->evA[set], 0));
             }
             if (e->n_sketch) {
-                const int rc = run_gemm2(0, e->Wtmp, e->mu, e->wmax, n, n_kb, outb, acc_now, set, rows, e->n_norm ? e->normacc : nullptr,
+                const int rc = run_gemm2(0, e->Wtmp, e->mu, e->wmax, n, n_kb, outb, acc_now, set, rows, e->n_norm ? e->vsq : nullptr,
                                          e->n_norm ? normb : nullptr, tab, false);
                 if (rc) return rc;
             }
@@ -2231,11 +2251,11 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                     ProfScope ps(e, stream, 1);
                     mid_dom1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->P2, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale,
                                                                          e->csum, (float)e->n_keep, e->cmu, e->Wtmp, e->Wtmp2, e->wmax, e->wmax2,
-                                                                         e->normacc2);
-                    if (e->n_norm && !e->n_sketch) add_norm_kernel<<<1, 64, 0, stream>>>(e->normacc2, normd, e->n_norm, acc_now);
+                                                                         e->vsq2);
+                    if (e->n_norm && !e->n_sketch) norm_reduce_kernel<<<e->n_norm, 256, 0, stream>>>(e->vsq2, e->n_norm, normd, tab);
                 }
                 if (e->n_sketch) {
-                    int rc = run_gemm2(0, e->Wtmp, e->cmu, e->wmax, n, n_kb, outd, acc_now, set, rows, e->n_norm ? e->normacc2 : nullptr,
+                    int rc = run_gemm2(0, e->Wtmp, e->cmu, e->wmax, n, n_kb, outd, acc_now, set, rows, e->n_norm ? e->vsq2 : nullptr,
                                        e->n_norm ? normd : nullptr, tab, false);
                     if (rc) return rc;
                     HIPCHK(hipMemsetAsync(e->corr, 0, 16 * kMaxTiles * sizeof(double), stream));
