@@ -99,7 +99,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from pyrhe_amd import engine as eng_mod
-    from pyrhe_amd.streaming import BlockPlan, SketchRunner, shard_ranges
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner, engine_capacity, shard_ranges
     from pyrhe_amd import estimate as est
 
     N, M, jn, k = args.n_indv, args.n_snp, args.jn, args.k
@@ -119,8 +119,8 @@ def main():
         eng_mod.recode_rows(geno, "value")       # the load-time recode of the product path (models.py), outside the timing
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
-    engine = eng_mod.SketchEngine(N, N, max_entries=plan.max_block, precision=args.precision, device=dev,
-                                  sub_snps=args.sub_snps)
+    engine = eng_mod.SketchEngine(N, N, max_entries=engine_capacity(plan), precision=args.precision, device=dev,
+                                  sub_snps=args.sub_snps or engine_capacity(plan))
     engine.set_coding(coding)
     np.random.seed(0)
     Z = np.random.randn(N, k)                                               # NumPy legacy stream, seed 0
@@ -129,7 +129,7 @@ def main():
         # heritable phenotype for the parity check between precision modes: y = a * (K r) + b * noise, K r = X X^T r / M
         r = np.random.default_rng(7).normal(size=(N, 1))
         # always built in the parity-safe mode, so that every --precision is verified on the SAME phenotype
-        eng_y = eng_mod.SketchEngine(N, N, max_entries=plan.max_block, precision="i8x3", device=dev, sub_snps=args.sub_snps)
+        eng_y = eng_mod.SketchEngine(N, N, max_entries=engine_capacity(plan), precision="i8x3", device=dev, sub_snps=args.sub_snps or engine_capacity(plan))
         eng_y.set_coding(coding)
         rr = SketchRunner(eng_y, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=r, seed=0, streaming=True)
         rr.begin_trait(y, check_missing=False)
@@ -149,8 +149,8 @@ def main():
         env = np.random.default_rng(3).integers(0, 2, size=N).astype(np.float64)     # Bernoulli(0.5)
         n_cols = (2 if cov is None else 4) * k + 2
         if n_cols > 30:                               # [Z, UZ | y] and [e.Z, e.UZ | e.y] on two engines
-            engines = [engine, eng_mod.SketchEngine(N, N, max_entries=plan.max_block, precision=args.precision, device=dev,
-                                                    sub_snps=args.sub_snps)]
+            engines = [engine, eng_mod.SketchEngine(N, N, max_entries=engine_capacity(plan), precision=args.precision, device=dev,
+                                                    sub_snps=args.sub_snps or engine_capacity(plan))]
             engines[1].set_coding(coding)
     runner = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, cov=cov, env=env,
                           genie_model=args.genie, seed=0, streaming=True,
@@ -191,8 +191,9 @@ def main():
     dom_ms = max(g1, g2)
     bytes_per_launch = local_snps * row_bytes / launches                    # algorithmic bytes: ceil(N/4) per SNP
     achieved = bytes_per_launch / (dom_ms / launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md), only
-    # when this run has the shape those passes were taken on (whole 10 000-SNP blocks at N = 500 000)
+    # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md): the measured
+    # bytes per algorithmic byte of that kernel times this run's algorithmic bytes per launch, only when this run has the
+    # shape those passes were taken on (10 000-SNP blocks at N = 500 000, one bin)
     traffic = None
     try:
         with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as fh:
@@ -200,7 +201,7 @@ def main():
         key = {"gemm1_kernel": "gemm1_i8_kernel" if args.precision == "i8x3" else "gemm1_kernel_f16",
                "gemm2_kernel": "gemm2_kernel_f16" if args.precision == "f16" else "gemm2_kernel_f16x2"}[dom]
         if N == tj["n_indv"] and M // jn == tj["block_snps"] and args.n_bin == 1:
-            traffic = tj["kernels"][key]["bytes"]
+            traffic = int(tj["kernels"][key]["bytes_per_algorithmic_byte"] * bytes_per_launch)
     except Exception:
         traffic = None
     # matrix-core work of the dominant kernel as issued (16-column tiles, all limbs / parts), beside the byte roofline:
@@ -258,7 +259,7 @@ def main():
         # headline, never as `value` -- its sigma^2 error is ~2^-12/sqrt(N k), not bounded by 1e-5 at every size
         del runner
         engine.close()
-        engine = eng_mod.SketchEngine(N, N, max_entries=plan.max_block, precision="f16", device=dev, sub_snps=args.sub_snps)
+        engine = eng_mod.SketchEngine(N, N, max_entries=engine_capacity(plan), precision="f16", device=dev, sub_snps=args.sub_snps or engine_capacity(plan))
         engine.set_coding(coding)
         runner = SketchRunner(engine, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True,
                               compat="fixed" if cov is not None else "reference")

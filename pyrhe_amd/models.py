@@ -25,7 +25,7 @@ from . import estimate as est
 from . import io as rio
 from .engine import SketchEngine, recode_rows, upload_packed
 from .logger import Logger
-from .streaming import n_engines_needed, BlockPlan, SketchRunner, shard_ranges
+from .streaming import engine_capacity, n_engines_needed, BlockPlan, SketchRunner, shard_ranges
 
 
 class Base:
@@ -128,8 +128,8 @@ class Base:
         self._runner = None
 
     def _new_engine(self) -> SketchEngine:
-        eng = SketchEngine(self.num_indv_original, self.num_indv, max_entries=self.plan.max_block,
-                           precision=self.precision, device=self.device, sub_snps=self._sub_snps)
+        eng = SketchEngine(self.num_indv_original, self.num_indv, max_entries=engine_capacity(self.plan),
+                           precision=self.precision, device=self.device, sub_snps=self._sub_snps or engine_capacity(self.plan))
         eng.set_coding("value")
         return eng
 

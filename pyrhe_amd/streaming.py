@@ -20,6 +20,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -98,6 +100,14 @@ class Systems:
 
 
 MAX_ENGINE_COLS = 30            # PYRHE_MAX_COLS of include/pyrhe_sketch.h
+MAX_SEGMENTS = 64               # kMaxSeg of the engine: (block, bin) lists one kernel chunk can hold
+
+
+def engine_capacity(plan: "BlockPlan") -> int:
+    """``max_entries`` / ``sub_snps`` to create the engines with: at least one block, and room (65 536 entries per kernel
+    chunk) to sketch several blocks in one call -- see SketchRunner.sketch_local_blocks.  Measured on MI355X
+    (16 384 -> 65 536): N=50k 71 -> 122 M SNPs/s, N=500k 15.3 -> 16.2 M; beyond that the gain flattens."""
+    return max(int(plan.max_block), int(os.environ.get("PYRHE_CAPACITY", "65536")))
 
 
 def plan_passes(k: int, n_groups: int, n_norm: int):
@@ -329,6 +339,35 @@ class SketchRunner:
             self._entries_cache[j] = (torch.from_numpy(cat).to(self.device), offs)
         return self._entries_cache[j]
 
+    def _blocks_per_call(self) -> int:
+        """Consecutive blocks sketched by ONE engine call.  A call takes any number of entry lists, so the (block, bin)
+        lists of several blocks can go in together: for small cohorts (N = 50k: 62 MB per block) that means one GEMM 1 /
+        GEMM 2 launch per ~3 blocks instead of per block.  Bounds: the lists of a batch fit one kernel chunk (entries and
+        segment table), the rows of a batch stay within the engine's 32-bit byte offsets."""
+        if self.dom:
+            return 1
+        cap = int(getattr(self.eng, "sub_snps", 0)) or self.plan.max_block
+        pitch = int(getattr(self.eng, "pitch", self.n_pad // 4))
+        by_entries = cap // max(self.plan.max_block, 1)
+        by_bytes = ((1 << 32) - 1) // max(self.plan.max_block * pitch, 1)
+        by_lists = MAX_SEGMENTS // max(self.plan.n_bin, 1)
+        return max(1, min(by_entries, by_bytes, by_lists))
+
+    def _batch_entries(self, js):
+        """Entry lists of the blocks ``js`` (consecutive) as ONE call: row indices relative to the first row of the batch,
+        offsets over the (block, bin) lists in block-major order."""
+        key = (js[0], js[-1])
+        if key not in self._entries_cache:
+            first = self.plan.range(js[0])[0]
+            ents, offs, pos = [], [0], 0
+            for j in js:
+                cat, o = self.plan.entries(j)
+                ents.append(cat + np.int32(self.plan.range(j)[0] - first))
+                offs.extend((pos + o[1:]).tolist())
+                pos += int(o[-1])
+            self._entries_cache[key] = (torch.from_numpy(np.concatenate(ents).astype(np.int32)).to(self.device), np.asarray(offs, np.int64))
+        return self._entries_cache[key]
+
     def sketch_local_blocks(self, out_sk, out_norm, pass_index: int = 0, after_block=None):
         """Enqueue the sketch of every local block: ``out_sk[p][jl]`` / ``out_norm[p][jl]`` receive the per-block
         outputs of engine pass p (``[nbin, n_sketch_p, n_pad]`` float32 / ``[nbin, n_norm_p]`` float64).  With a
@@ -340,26 +379,44 @@ class SketchRunner:
         for eng in pipelined:
             eng.set_async(True)       # blocks write distinct outputs: let GEMM 1 of block j+1 overlap GEMM 2 of block j
         fills = []                    # keep fill tensors alive until the join
+        B = 1 if one_slot else self._blocks_per_call()
+        nb = self.plan.n_bin
         try:
-            for jl_i, j in enumerate(range(self.j0, self.j1)):
-                jl = 0 if one_slot else jl_i
-                ent, offs = self._entries(j)
-                s, e = self.plan.range(j)
+            local = list(range(self.j0, self.j1))
+            for jl0 in range(0, len(local), B):
+                js = local[jl0:jl0 + B]
+                jl = 0 if one_slot else jl0
+                if len(js) == 1:
+                    ent, offs = self._entries(js[0])
+                else:
+                    ent, offs = self._batch_entries(js)
+                s = self.plan.range(js[0])[0]
+                e = self.plan.range(js[-1])[1]
+                rows = self.geno[s - self.row0: e - self.row0]
                 fill = None
                 if any_missing:
-                    u = draw(j, e - s)                    # one uniform per SNP, missing or not (base.py:266,285)
-                    fill = self._fill_for_block(j, u)
-                    fills.append(fill)
+                    parts = []
+                    for j in js:
+                        sj, ej = self.plan.range(j)
+                        f = self._fill_for_block(j, draw(j, ej - sj))      # one uniform per SNP, missing or not (base.py:266,285)
+                        parts.append((f, ej - sj))
+                    if any(f is not None for f, _ in parts):      # blocks without a missing call need no fill path
+                        fill = torch.cat([f if f is not None else torch.zeros(m_, dtype=torch.float32, device=self.device)
+                                          for f, m_ in parts]) if len(parts) > 1 else parts[0][0]
+                        fills.append(fill)
                 for p in range(self.n_pass):
                     if self.dom:
-                        self.engs[p].sketch_block_dom(self._block_rows(j), ent, offs, fill=fill, out_sketch=out_sk[p][jl],
+                        self.engs[p].sketch_block_dom(rows, ent, offs, fill=fill, out_sketch=out_sk[p][jl],
                                                       out_norm=out_norm[p][jl], out_sketch_dom=self.blocks_skd[p][jl],
                                                       out_norm_dom=self.blocks_nmd[p][jl], accumulate=False)
                     else:
-                        self.engs[p].sketch_block(self._block_rows(j), ent, offs, fill=fill, out_sketch=out_sk[p][jl],
-                                                  out_norm=out_norm[p][jl], accumulate=False)
+                        n = len(js)
+                        osk = out_sk[p][jl:jl + n]
+                        onm = out_norm[p][jl:jl + n]
+                        self.engs[p].sketch_block(rows, ent, offs, fill=fill, out_sketch=osk.reshape(n * nb, *osk.shape[2:]),
+                                                  out_norm=onm.reshape(n * nb, onm.shape[2]), accumulate=False)
                 if one_slot:
-                    after_block(jl_i, j)
+                    after_block(jl0, js[0])
         finally:
             for eng in pipelined:
                 eng.join()
