@@ -17,7 +17,7 @@ cov = None
 if ncov:
     cov = np.concatenate([np.ones((N, 1)), np.random.default_rng(2).normal(size=(N, ncov - 1))], axis=1)
 engine = eng_mod.SketchEngine(N, N, max_entries=plan.max_block, device=dev)
-runner = SketchRunner(engine, geno, plan, (0, jn), n_orig=N, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True,
+runner = SketchRunner(engine, geno, plan, (0, jn), n_orig=N, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True, dom=bool(os.environ.get("DOM")),
                       compat=os.environ.get("COMPAT", "fixed" if cov is not None else "reference"))
 runner.begin_trait(y, check_missing=False)
 runner.pass1(); torch.cuda.synchronize()
