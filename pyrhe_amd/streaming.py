@@ -583,6 +583,7 @@ class SketchRunner:
             return self._pass2()
 
     def _pass2(self) -> Systems:
+        self._tot_dots = {}              # whole-data inner products, valid for this pass only (see _dots)
         plan, k, ne = self.plan, self.k, self.n_est
         jn, nb = plan.n_jack, plan.n_bin
         use_cov = self.cov is not None
@@ -759,6 +760,21 @@ class SketchRunner:
         yi = [i for i, r in enumerate(y) if r is not None]
         if not xi or not yi:
             return torch.zeros((batch, len(x), len(y)), dtype=torch.float64, device=self.device)
+        # products of whole-data rows only do not depend on the block: computed once per pass 2 (the batch of
+        # leave-one-out slots, the whole-data slot and -- when blocks are re-sketched -- every block ask for the same)
+        key = None
+        if batch == 1 and all(r is None or r.blk is None for r in x) and all(r is None or r.blk is None for r in y):
+            key = (tuple(None if r is None else r.tot.data_ptr() for r in x),
+                   tuple(None if r is None else r.tot.data_ptr() for r in y), n_sub)
+            hit = self._tot_dots.get(key)
+            if hit is not None:
+                return hit
+            out = self._dots_uncached(x, y, xi, yi, n_sub, batch)
+            self._tot_dots[key] = out
+            return out
+        return self._dots_uncached(x, y, xi, yi, n_sub, batch)
+
+    def _dots_uncached(self, x, y, xi, yi, n_sub, batch):
         res = self.eng.loo_dots([x[i] for i in xi], [y[i] for i in yi], self.n_pad, n_sub, batch)
         if len(xi) == len(x) and len(yi) == len(y):
             return res
