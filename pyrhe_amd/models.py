@@ -157,7 +157,21 @@ class Base:
         if self._runner is None:
             self._runner = self._make_runner()
         self.num_estimates = self.get_num_estimates()
-        self.systems = self._runner.run_trait(self.pheno[:, 0])
+        trait = getattr(self, "_cur_trait", None)
+        cache = self.__dict__.setdefault("_trait_systems", {})
+        if trait is None:
+            self.systems = self._runner.run_trait(self.pheno[:, 0])
+        else:
+            if trait not in cache:
+                # The sketches do not depend on the phenotype: this phenotype and the following ones (as many as the spare
+                # right-hand columns of one pass take) share both passes; their systems differ in q only.  The reference
+                # repeats the whole computation per phenotype with identical intermediate results.
+                group = list(range(trait, min(self.pheno_cp.shape[1], trait + self._runner.max_traits())))
+                from .streaming import Systems
+                sysm = self._runner.run_trait(self.pheno_cp[:, group])
+                for i, t_ in enumerate(group):
+                    cache[t_] = Systems(sysm.T, sysm.q_all[i], sysm.M, sysm.q_all[i:i + 1])
+            self.systems = cache[trait]
         self.M = self.systems.M
         self.log._debug(f"Precompute total time: {time.time() - t0}")
 
@@ -195,7 +209,11 @@ class Base:
         self.pheno = self.pheno_cp[:, trait].reshape(-1, 1)
         self.log._log("*****")
         self.log._log(f"OUTPUT FOR TRAIT {trait}: ")
-        self.pre_compute()
+        self._cur_trait = int(trait)
+        try:
+            self.pre_compute()
+        finally:
+            self._cur_trait = None
         return self.run(method=method)
 
     def run(self, method):

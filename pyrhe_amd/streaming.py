@@ -94,9 +94,10 @@ def hwe_fill_values(sum_obs: np.ndarray, n_obs: np.ndarray, uniforms: np.ndarray
 @dataclass
 class Systems:
     """Normal equations of every jackknife slot: rows 0..jn-1 leave block j out, row jn is the whole data."""
-    T: np.ndarray        # [jn+1, ne+1, ne+1]
-    q: np.ndarray        # [jn+1, ne+1]
+    T: np.ndarray        # [jn+1, ne+1, ne+1]   (does not depend on the phenotype)
+    q: np.ndarray        # [jn+1, ne+1]         first phenotype of the run
     M: np.ndarray        # [jn+1, ne]
+    q_all: Optional[np.ndarray] = None   # [n_traits, jn+1, ne+1]: every phenotype sketched in the same pass
 
 
 MAX_ENGINE_COLS = 30            # PYRHE_MAX_COLS of include/pyrhe_sketch.h
@@ -235,12 +236,16 @@ class SketchRunner:
         """Columns handed to the engine(s).  Sketch groups of k columns: Z, [UZ] and for G x E e.Z, [e.UZ];
         norm columns: y~ and e.y~  (X_e^T r = X^T (e . r), X_e v = e . (X v); streaming_genie.py:33-49)."""
         use_cov = self.cov is not None
-        y64 = np.asarray(y, np.float64).reshape(-1)
-        if use_cov:          # regress_pheno (base.py:396-401), float64 on the host
+        y64 = np.asarray(y, np.float64)
+        y64 = y64.reshape(-1, 1) if y64.ndim == 1 else y64                       # [N, n_traits]
+        if use_cov:          # regress_pheno (base.py:396-401), float64 on the host, phenotype by phenotype
             W = self.cov
-            y64 = y64 - W @ (np.linalg.pinv(W.T @ W) @ (W.T @ y64))
+            y64 = np.stack([y64[:, t] - W @ (np.linalg.pinv(W.T @ W) @ (W.T @ y64[:, t])) for t in range(y64.shape[1])], axis=1)
         self.y_res = y64
-        ypad = self._pad_cols(torch.from_numpy(y64[None, :]))
+        self.n_traits = nt = y64.shape[1]
+        if nt > self.max_traits():
+            raise ValueError(f"{nt} phenotypes do not fit the spare right-hand columns of one pass ({self.max_traits()})")
+        ypad = self._pad_cols(torch.from_numpy(np.ascontiguousarray(y64.T)))     # [n_traits, n_pad]
         names, groups, norms = ["Z"], [self.Z64], [ypad]
         if use_cov:
             names.append("UZ"); groups.append(self.UZ64)
@@ -251,7 +256,7 @@ class SketchRunner:
                 names.append("eUZ"); groups.append(self.UZ64 * e)
             norms.append(ypad * e)
         k = self.k
-        passes = plan_passes(k, len(groups), len(norms))
+        passes = plan_passes(k, len(groups), sum(n.shape[0] for n in norms))
         if len(passes) > len(self.engs):
             raise RuntimeError(f"{len(groups)} groups of {k} right-hand columns need {len(passes)} engines, "
                                f"{len(self.engs)} given")
@@ -270,10 +275,10 @@ class SketchRunner:
             sk = torch.cat(parts, dim=0).to(torch.float32) if parts else None
             nm = torch.cat(norms, dim=0).to(torch.float32) if pi == 0 else None
             self.engs[pi].set_rhs(sk, nm, self.keep)
-            self.pass_shapes.append((col, len(norms) if pi == 0 else 0))
-        self.loc["y"] = (0, 0)
+            self.pass_shapes.append((col, sum(n.shape[0] for n in norms) if pi == 0 else 0))
+        self.loc["y"] = (0, 0)                 # norm columns of pass 0: y of every phenotype, then e.y of every phenotype
         if self.n_gxe:
-            self.loc["ey"] = (0, 1)
+            self.loc["ey"] = (0, nt)
         self.n_pass = len(passes)
         bl = sorted(breaks)
         self.intervals = [(bl[i], bl[i + 1] - bl[i]) for i in range(len(bl) - 1)]
@@ -432,8 +437,18 @@ class SketchRunner:
         out = ((x @ W) @ Q.T) @ W.T
         return out.reshape(shp).to(torch.float64)
 
+    def max_traits(self) -> int:
+        """Phenotypes one pass can take: the sketches X X^T Z do not depend on the phenotype, a phenotype only adds a norm
+        column (two with G x E), so the spare right-hand columns of the first engine pass carry further phenotypes for free
+        (k = 10: 20 without covariates, 10 with; the reference re-runs everything per phenotype)."""
+        n_groups = (2 if self.cov is not None else 1) * (2 if self.n_gxe else 1)
+        per = 2 if self.n_gxe else 1
+        used = sum(nc for _, _, nc in plan_passes(self.k, n_groups, per)[0])
+        return max(1, (MAX_ENGINE_COLS - used) // per)
+
     def run_trait(self, y: np.ndarray, check_missing: bool = True) -> Systems:
-        """Pass 1 + pass 2 for one centred phenotype ``y [N]``; returns the jn+1 normal-equation systems (every rank)."""
+        """Pass 1 + pass 2 for one centred phenotype ``y [N]`` -- or several, ``y [N, n_traits <= max_traits()]``, which
+        share both passes; returns the jn+1 normal-equation systems (every rank), ``q_all`` holding every phenotype's."""
         self.begin_trait(y, check_missing)
         self.pass1()
         return self.pass2()
@@ -466,18 +481,19 @@ class SketchRunner:
         return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
     def _block_estimates(self, sk_list, nm_list, skd_list=None, nmd_list=None):
-        """A = XXz, C = XXUz ``[ne_g, k, n_pad]`` and r = yXXy ``[ne_g]`` of the genotype-derived estimates (G bins,
+        """A = XXz, C = XXUz ``[ne_g, k, n_pad]`` and r = yXXy ``[ne_g, n_traits]`` of the genotype-derived estimates (G bins,
         then dominance bins or G x E bins) from engine outputs of one block; float64."""
         f64 = torch.float64
         A = self._group(sk_list, "Z").to(f64)
         C = self._group(sk_list, "UZ").to(f64) if self.cov is not None else None
         py, cy = self.loc["y"]
-        r = nm_list[py][:, cy]
+        nt = self.n_traits
+        r = nm_list[py][:, cy:cy + nt]                                   # [nb, n_traits]
         if self.dom:
             A = torch.cat([A, self._group(skd_list, "Z").to(f64)], dim=0)
             if C is not None:
                 C = torch.cat([C, self._group(skd_list, "UZ").to(f64)], dim=0)
-            r = torch.cat([r, nmd_list[py][:, cy]], dim=0)
+            r = torch.cat([r, nmd_list[py][:, cy:cy + nt]], dim=0)
         if self.n_gxe:
             e = self.env_pad
             # elem_mul(X, env) then float32 GEMVs in the reference (streaming_genie.py:39-41): X_e X_e^T z = e.(X X^T (e.z))
@@ -489,7 +505,7 @@ class SketchRunner:
                 Ce = (gu * e.to(gu.dtype)).to(f64)
                 C = torch.cat([C, Ce], dim=0)
             pe, ce = self.loc["ey"]
-            r = torch.cat([r, nm_list[pe][:, ce]], dim=0)
+            r = torch.cat([r, nm_list[pe][:, ce:ce + nt]], dim=0)
         return A, C, r
 
     def _nxe_sketch(self):
@@ -498,9 +514,9 @@ class SketchRunner:
         f32, f64 = torch.float32, torch.float64
         e32 = self.env_pad.to(f32)
         A = (e32 * (e32 * self.Z64.to(f32))).to(f64)[None]                 # [1, k, n_pad]
-        ypad = self._pad_cols(torch.from_numpy(self.y_res[None, :]))[0]
-        v = e32 * ypad.to(f32)
-        r = (v.to(f64) @ v.to(f64)).to(f32).to(f64).reshape(1)
+        ypad = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.y_res.T)))      # [n_traits, n_pad]
+        v = (e32 * ypad.to(f32)).to(f64)
+        r = (v * v).sum(dim=1).to(f32).to(f64).reshape(1, -1)                             # [1, n_traits]
         C = (e32 * (e32 * self.UZ64.to(f32))).to(f64)[None] if self.cov is not None else None
         return A, C, r
 
@@ -600,7 +616,7 @@ class SketchRunner:
             if self.n_nxe:
                 blk[-1] = 0
             M[j] = last - blk
-        yy = float(self.y_res @ self.y_res)
+        yy = (self.y_res * self.y_res).sum(axis=0)                 # [n_traits]
 
         tot_A, tot_C, tot_r, D_tot = self.tot_A, self.tot_C, self.tot_r, self.D_tot
         nxe = self._nxe_sketch() if (self.n_nxe or self.quirk_last_total) else None
@@ -629,7 +645,12 @@ class SketchRunner:
             return A, C, D, r
 
         if self.pass2_impl == "torch":
-            return self._pass2_torch(M, yy, tot_A, tot_C, D_tot, tot_r, nxe, with_nxe)
+            if self.n_traits != 1:
+                raise ValueError("the materialised cross-check path takes one phenotype")
+            nxe1 = None if nxe is None else (nxe[0], nxe[1], nxe[2][:, 0])
+            if nxe is not None:
+                nxe = nxe1
+            return self._pass2_torch(M, float(yy[0]), tot_A, tot_C, D_tot, tot_r[:, 0], nxe, with_nxe)
         # ---- on-device assembly: every inner product of a slot comes from pyrhe_engine_loo_dots, whole batches of
         # blocks per call; only [batch, ne, ne]-sized results reach the host
         tots = (tot_A, tot_C, D_tot, tot_r)
@@ -658,8 +679,9 @@ class SketchRunner:
             local = [item for part in gathered for item in part]
         local.sort(key=lambda t: t[0])
         Ts = np.stack([t[1] for t in local] + [T_tot])
-        qs = np.stack([t[2] for t in local] + [q_tot])
-        return Systems(Ts, qs, M)
+        qs = np.stack([t[2] for t in local] + [q_tot])           # [jn+1, n_traits, ne+1]
+        q_all = np.ascontiguousarray(np.transpose(qs, (1, 0, 2)))
+        return Systems(Ts, q_all[0], M, q_all)
 
     def _pass2_torch(self, M, yy, tot_A, tot_C, D_tot, tot_r, nxe, with_nxe):
         """The same systems from materialised leave-one-out arrays and torch reductions: slow (degenerate GEMM shapes),
@@ -673,6 +695,7 @@ class SketchRunner:
                 T, q = self._system(*with_nxe(tot_A, tot_C, D_tot, tot_r), M[jn], yy)
             else:
                 A, C, r = self._block_estimates(*stored)
+                r = r[:, 0]
                 D = None
                 if use_cov:
                     D = D_tot - self._apply_U(A, f32=True)      # streaming_rhe.py:35-36
@@ -848,29 +871,30 @@ class SketchRunner:
             cd = gCD - flat(PC @ Q) @ flat(PbA).transpose(1, 2)
             gram = gram + cd - 2.0 * uaa
         # r = yXXy: whole-data minus block
-        r = tot_r[None, :].expand(batch, -1)
+        nt = self.n_traits
+        r = tot_r[None].expand(batch, -1, -1)                     # [batch, ne_g, n_traits]
         if store is not None:
             py, cy = self.loc["y"]
-            parts = [store[1][py][:batch, :, cy]]
+            parts = [store[1][py][:batch, :, cy:cy + nt]]
             if self.dom:
-                parts.append(store[3][py][:batch, :, cy])
+                parts.append(store[3][py][:batch, :, cy:cy + nt])
             if self.n_gxe:
                 pe, ce = self.loc["ey"]
-                parts.append(store[1][pe][:batch, :, ce])
+                parts.append(store[1][pe][:batch, :, ce:ce + nt])
             r = r - torch.cat(parts, dim=1)
         if self.n_nxe:
-            r = torch.cat([r, nxe[2][None, :].expand(batch, 1)], dim=1)
+            r = torch.cat([r, nxe[2][None].expand(batch, 1, nt)], dim=1)
         # one copy back: gram | tz | tk | r  -- no host->device traffic and no intermediate synchronisation in here; the
         # division by the SNP counts is host arithmetic on [batch, ne, ne]
-        cols = [gram.reshape(batch, -1), r]
+        cols = [gram.reshape(batch, -1), r.reshape(batch, -1)]
         if tz is not None:
             cols.append(tz.expand(batch, -1) if tz.shape[0] != batch else tz)
         if tk is not None:
             cols.append(tk.expand(batch, -1) if tk.shape[0] != batch else tk)
         host = self._to_host(torch.cat(cols, dim=1))
         gram_h = host[:, :ne * ne].reshape(batch, ne, ne)
-        r_h = host[:, ne * ne:ne * ne + ne]
-        off = ne * ne + ne
+        r_h = host[:, ne * ne:ne * ne + ne * nt].reshape(batch, ne, nt)
+        off = ne * ne + ne * nt
         tz_h = tk_h = None
         if tz is not None:
             tz_h = host[:, off:off + ne]; off += ne
@@ -878,7 +902,7 @@ class SketchRunner:
             tk_h = host[:, off:off + ne]
         Mf = M_rows.astype(np.float64)                            # [batch, ne]
         T = np.zeros((batch, ne + 1, ne + 1))
-        q = np.zeros((batch, ne + 1))
+        q = np.zeros((batch, nt, ne + 1))                        # one right-hand side per phenotype, T is shared
         mm = Mf[:, :, None] * Mf[:, None, :]
         with np.errstate(divide="ignore", invalid="ignore"):
             T[:, :ne, :ne] = np.where(mm != 0, gram_h / k / mm, 0.0)
@@ -887,11 +911,11 @@ class SketchRunner:
                 tr[:, nb:] = tz_h[:, nb:] / (k * Mf[:, nb:])       # stochastic trace of a GxE / NxE kernel (genie.py:85-89)
             if use_cov:
                 tr = tr - tk_h / (k * Mf)                          # base.py:614-615
-            q[:, :ne] = np.where(Mf != 0, r_h / Mf, 0.0)
+            q[:, :, :ne] = np.transpose(np.where(Mf[:, :, None] != 0, r_h / Mf[:, :, None], 0.0), (0, 2, 1))
         T[:, :ne, ne] = tr
         T[:, ne, :ne] = tr
         T[:, ne, ne] = self.N - (self.cov.shape[1] if use_cov else 0)
-        q[:, ne] = yy
+        q[:, :, ne] = np.asarray(yy)[None, :]
         return T, q
 
     def _stored_block(self, jl_i: int):

@@ -222,3 +222,45 @@ def test_store_falls_back_to_one_slot_when_hbm_is_short(monkeypatch):
         out.append(sysm)
         eng.close()
     assert np.allclose(out[0].T, out[1].T, rtol=1e-9) and np.allclose(out[0].q, out[1].q, rtol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["rhe", "rhe_cov", "genie_nxe_cov", "dom"])
+def test_phenotypes_sharing_one_pass_equal_separate_runs(case):
+    """Several phenotypes as norm columns of ONE pass (the sketches do not depend on the phenotype): T identical, q equal to
+    the one-phenotype runs -- every model family, the N x E closed form and the reference-compatible UXXz included."""
+    from pyrhe_amd import engine
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner, n_engines_needed
+    dev = torch.device("cuda", 0)
+    n, m, jn, k, nt = 3000, 600, 6, 10, 4
+    geno = engine.recode_rows(engine.synth_genotypes(m, n, SEED, 31, dev), "value")
+    rng = np.random.default_rng(12)
+    annot = np.zeros((m, 2), np.int64)
+    annot[np.arange(m), rng.integers(0, 2, m)] = 1
+    plan = BlockPlan(annot, jn)
+    np.random.seed(0)
+    Z = np.random.randn(n, k)
+    Y = rng.normal(size=(n, nt)); Y -= Y.mean(axis=0)
+    kw = dict(n_orig=n, missing_indv=[], Z=Z, seed=0, streaming=True, compat="reference")
+    has_gxe = False
+    if case in ("rhe_cov", "genie_nxe_cov"):
+        kw["cov"] = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, 2))], axis=1)
+    if case == "genie_nxe_cov":
+        kw.update(env=rng.integers(0, 2, n).astype(np.float64), genie_model="G+GxE+NxE")
+        has_gxe = True
+    if case == "dom":
+        kw["dom"] = True
+    engs = []
+    for _ in range(n_engines_needed(k, "cov" in kw, has_gxe)):
+        e_ = engine.SketchEngine(n, n, plan.max_block, device=dev)
+        e_.set_coding("value")
+        engs.append(e_)
+    runner = SketchRunner(engs, geno, plan, (0, jn), **kw)
+    assert runner.max_traits() >= nt
+    both = runner.run_trait(Y, check_missing=False)
+    assert both.q_all.shape == (nt, jn + 1, both.T.shape[1])
+    for t in range(nt):
+        one = runner.run_trait(Y[:, t], check_missing=False)
+        assert np.allclose(one.T, both.T, rtol=1e-12, atol=0)
+        assert np.allclose(one.q, both.q_all[t], rtol=1e-12, atol=0), t
+    for e_ in engs:
+        e_.close()
