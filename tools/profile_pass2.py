@@ -12,7 +12,8 @@ geno = eng_mod.synth_genotypes(M, N, 1, 0, dev)
 annot = np.zeros((M, nbin), np.int8); annot[np.arange(M), np.arange(M) % nbin] = 1
 plan = BlockPlan(annot, jn)
 np.random.seed(0); Z = np.random.randn(N, k)
-y = np.random.default_rng(1).normal(size=N); y -= y.mean()
+NT = int(os.environ.get('NT', 1))
+y = np.random.default_rng(1).normal(size=(N, NT)) if NT > 1 else np.random.default_rng(1).normal(size=N); y -= y.mean(axis=0)
 cov = None
 if ncov:
     cov = np.concatenate([np.ones((N, 1)), np.random.default_rng(2).normal(size=(N, ncov - 1))], axis=1)
