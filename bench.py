@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--n-cov", type=int, default=0, help="covariate columns incl. intercept (configs[3]: 11)")
     ap.add_argument("--genie", default=None, choices=["G+GxE", "G+GxE+NxE"],
                     help="StreamingGENIE sketch pass with one Bernoulli(0.5) environment (BASELINE configs[4])")
-    ap.add_argument("--precision", default=os.environ.get("PYRHE_PRECISION", "i8x3"), choices=["f16", "f16x2", "f16e", "i8x3"])
+    ap.add_argument("--precision", default=os.environ.get("PYRHE_PRECISION", "i8x3"), choices=["f16", "f16x2", "f16e", "i8x3", "i8f16"])
     ap.add_argument("--sub-snps", type=int, default=int(os.environ.get("PYRHE_SUB_SNPS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-snps", type=int, default=0, help="SNPs in the CPU baseline sample (0 = auto)")
@@ -229,7 +229,7 @@ def main():
     out = {"metric": "SNPs/sec through streaming trace sketch (N=500k, k=10, jn=100)", "value": value, "unit": "SNPs/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": {"f16x2": "f16x2", "i8x3": "i8x3+f16x2", "f16": "f16", "f16e": "f16"}[args.precision], "data": "synthetic",
+           "dtype": {"f16x2": "f16x2", "i8x3": "i8x3+f16x2", "f16": "f16", "f16e": "f16", "i8f16": "i8x3+f16"}[args.precision], "data": "synthetic",
            "config": {"workload": f"synthetic N={N} M={M} {args.n_bin}-bin "
                                   + (f"StreamingGENIE {args.genie} (1 environment)" if args.genie else "StreamingRHE")
                                   + f" sketch pass, k={k} jn={jn}" + (f", {args.n_cov} covariates" if args.n_cov else ""),

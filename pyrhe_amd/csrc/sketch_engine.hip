@@ -1420,7 +1420,7 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     if (n_keep <= 0 || n_keep > 4 * pitch) return fail(PYRHE_EINVAL, "n_keep (%lld) must be in 1..4*pitch", (long long)n_keep);
     if (n_keep >= (1 << 23)) return fail(PYRHE_EINVAL, "n_keep (%lld) >= 2^23: genotype sums would not be exact in float32", (long long)n_keep);
     if (precision != PYRHE_PREC_F16 && precision != PYRHE_PREC_F16X2 && precision != PYRHE_PREC_F16_EXACT &&
-        precision != PYRHE_PREC_I8X3)
+        precision != PYRHE_PREC_I8X3 && precision != PYRHE_PREC_I8X3_F16)
         return fail(PYRHE_EINVAL, "unknown precision %d", precision);
     if (max_entries <= 0) return fail(PYRHE_EINVAL, "max_entries must be positive");
     HIPCHK(hipSetDevice(device));
@@ -1433,8 +1433,8 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     e->n_pad = 4 * pitch;
     e->precision = precision;
     e->parts = (precision == PYRHE_PREC_F16X2 || precision == PYRHE_PREC_I8X3) ? 2 : 1;
-    e->exact = precision != PYRHE_PREC_F16;
-    e->i8 = precision == PYRHE_PREC_I8X3;
+    e->exact = precision != PYRHE_PREC_F16 && precision != PYRHE_PREC_I8X3_F16;
+    e->i8 = precision == PYRHE_PREC_I8X3 || precision == PYRHE_PREC_I8X3_F16;
     if (sub_snps <= 0) {
         // Whole blocks per kernel pair.  Measured on MI355X (tools/microbench.hip E2): re-reading a sub-block that
         // was just streamed (Infinity Cache) is at most ~20 % faster than HBM, while short launches lose more than
@@ -1457,7 +1457,7 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     const size_t S = (size_t)sub_snps;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-    const size_t oP = carve(S * ncolmax * sizeof(float) * (precision == PYRHE_PREC_I8X3 ? 3 : 1));
+    const size_t oP = carve(S * ncolmax * sizeof(float) * (e->i8 ? 3 : 1));
     static_assert(kSegCols == 16 * kMaxTiles, "segment slots hold one value per logical column");
     const size_t oWmax = carve((size_t)kMaxSeg * kSegCols * sizeof(uint32_t));
     const size_t oCorr = carve((size_t)kMaxSeg * kSegCols * sizeof(double));

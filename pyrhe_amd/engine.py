@@ -19,7 +19,7 @@ PREC_F16 = 0
 PREC_F16X2 = 1
 PREC_F16_EXACT = 2
 PREC_I8X3 = 3
-PRECISIONS = {"f16": PREC_F16, "f16x2": PREC_F16X2, "f16e": PREC_F16_EXACT, "i8x3": PREC_I8X3}
+PRECISIONS = {"f16": PREC_F16, "f16x2": PREC_F16X2, "f16e": PREC_F16_EXACT, "i8x3": PREC_I8X3, "i8f16": 4}
 COL_SKETCH = 1
 COL_NORM = 2
 ROW_ALIGN = 256           # pitch granularity (bytes)

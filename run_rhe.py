@@ -69,7 +69,7 @@ def build_parser():
     p.add_argument("--debug_output", type=str, default="test")
     p.add_argument("--config", type=str, help="Configuration file path")
     # MI355X build
-    p.add_argument("--precision", type=str, default="i8x3", choices=["i8x3", "f16x2", "f16", "f16e"])
+    p.add_argument("--precision", type=str, default="i8x3", choices=["i8x3", "f16x2", "f16", "f16e", "i8f16"])
     p.add_argument("--compat", type=str, default="reference", choices=["reference", "fixed"])
     p.add_argument("--recompute_pass2", action="store_true")
     return p
