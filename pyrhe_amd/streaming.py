@@ -242,6 +242,7 @@ class SketchRunner:
             W = self.cov
             y64 = np.stack([y64[:, t] - W @ (np.linalg.pinv(W.T @ W) @ (W.T @ y64[:, t])) for t in range(y64.shape[1])], axis=1)
         self.y_res = y64
+        self.yy = np.einsum("ij,ij->j", y64, y64)                                # y~^T y~ per phenotype (base.py:625-626)
         self.n_traits = nt = y64.shape[1]
         if nt > self.max_traits():
             raise ValueError(f"{nt} phenotypes do not fit the spare right-hand columns of one pass ({self.max_traits()})")
@@ -616,7 +617,7 @@ class SketchRunner:
             if self.n_nxe:
                 blk[-1] = 0
             M[j] = last - blk
-        yy = (self.y_res * self.y_res).sum(axis=0)                 # [n_traits]
+        yy = self.yy                                               # [n_traits]
 
         tot_A, tot_C, tot_r, D_tot = self.tot_A, self.tot_C, self.tot_r, self.D_tot
         nxe = self._nxe_sketch() if (self.n_nxe or self.quirk_last_total) else None
