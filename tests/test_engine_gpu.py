@@ -306,3 +306,61 @@ def test_more_bins_than_one_segment_table(dev):
         assert (sk[b] - s1[0]).abs().max().item() <= 2e-6 * s1.abs().max().item(), b
         assert torch.allclose(nm[b], n1[0], rtol=1e-6), b
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_against_dense_float64(dev, seed):
+    """Randomised small cohorts (sample counts that are not multiples of 4 / 16 / 256, dropped individuals, 1-90 SNPs,
+    1-5 overlapping / empty bins, missing calls with random fills, both codings, both parity-safe precisions, with and
+    without a second column tile): sketch, norms and genotype sums against a dense float64 evaluation of the definition."""
+    from pyrhe_amd import engine
+    rng = np.random.default_rng(1000 + seed)
+    n0 = int(rng.integers(5, 900))
+    m = int(rng.integers(1, 90))
+    nbin = int(rng.integers(1, 6))
+    k = int(rng.choice([1, 3, 10, 17]))
+    precision = ["i8x3", "f16x2"][seed % 2]
+    coding = ["plink", "value"][(seed // 2) % 2]
+    drop = np.sort(rng.choice(n0, size=int(rng.integers(0, max(1, n0 // 10))), replace=False))
+    keep_idx = np.setdiff1d(np.arange(n0), drop)
+    n = len(keep_idx)
+    p = rng.uniform(0.1, 0.9, m)
+    geno = (rng.random((m, n0)) < p[:, None]).astype(np.int8) + (rng.random((m, n0)) < p[:, None]).astype(np.int8)
+    miss = rng.random((m, n0)) < (0.03 if seed % 3 == 0 else 0.0)
+    g_in = np.where(miss, -1, geno)
+    packed = plink.encode_bed_rows(g_in)
+    fill = rng.integers(0, 3, m).astype(np.float32)
+    G = np.where(miss, fill[:, None], geno).astype(np.float64)[:, keep_idx]            # [m, n] after filling
+    ok = (G.sum(1) > 0) & (G.sum(1) < 2 * n)                                         # the reference has no zero-variance guard
+    lists = [np.sort(rng.choice(np.nonzero(ok)[0], size=int(rng.integers(0, ok.sum() + 1)), replace=False)).astype(np.int32)
+             if ok.any() else np.zeros(0, np.int32) for _ in range(nbin)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+    eng = engine.SketchEngine(n0, n, max_entries=max(m, 1), precision=precision, device=dev)
+    buf = engine.upload_packed(packed, dev)
+    if coding == "value":
+        engine.recode_rows(buf, "value")
+        eng.set_coding("value")
+    keep = eng.keep_vector(list(drop))
+    Z = np.zeros((k, eng.n_pad), np.float32); Z[:, keep_idx] = rng.standard_normal((k, n)).astype(np.float32)
+    Y = np.zeros((2, eng.n_pad), np.float32); Y[:, keep_idx] = rng.standard_normal((2, n)).astype(np.float32)
+    eng.set_rhs(torch.from_numpy(Z).to(dev), torch.from_numpy(Y).to(dev), keep)
+    ent = torch.from_numpy(np.concatenate(lists) if offs[-1] else np.zeros(0, np.int32)).to(dev)
+    sk, nm, cs = eng.sketch_block(buf, ent, offs, fill=torch.from_numpy(fill).to(dev) if miss.any() else None, want_colsum=True)
+    torch.cuda.synchronize()
+    sk, nm, cs = sk.cpu().numpy(), nm.cpu().numpy(), cs.cpu().numpy()
+    for b, lst in enumerate(lists):
+        if len(lst) == 0:
+            assert not sk[b].any() and not nm[b].any()
+            continue
+        Gb = G[lst]
+        mu = (Gb.sum(1).astype(np.float32) / np.float32(n))
+        d = (np.float32(1) / np.sqrt(mu * (np.float32(1) - np.float32(0.5) * mu))).astype(np.float64)
+        X = ((Gb - mu[:, None].astype(np.float64)) * d[:, None]).T                    # [n, m_b]
+        ref = (X @ (X.T @ Z[:, keep_idx].T.astype(np.float64))).T                     # [k, n]
+        refn = ((X.T @ Y[:, keep_idx].T.astype(np.float64)) ** 2).sum(0)
+        assert np.array_equal(cs[offs[b]:offs[b + 1]], Gb.sum(1).astype(np.int64))
+        scale = np.abs(ref).max() + 1e-30
+        assert np.abs(sk[b][:, keep_idx] - ref).max() <= 2e-5 * scale, (b, np.abs(sk[b][:, keep_idx] - ref).max() / scale)
+        assert np.allclose(nm[b], refn, rtol=2e-5)
+        assert not sk[b][:, np.setdiff1d(np.arange(eng.n_pad), keep_idx)].any()
+    eng.close()
