@@ -7,7 +7,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = [os.path.join(CSRC, "sketch_engine.hip")]
+SOURCES = [os.path.join(CSRC, "sketch_engine.hip")]                 # one translation unit ...
+INCLUDED = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".inc", ".h")))   # ... of these pieces
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pyrhe_sketch.h")
 LIB = os.path.join(CSRC, "libpyrhe_sketch.so")
 
@@ -20,7 +21,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in SOURCES + [HEADER])
+    return any(os.path.getmtime(p) > t for p in SOURCES + INCLUDED + [HEADER])
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:

@@ -1,7 +1,7 @@
 """ctypes binding of the C ABI in ``include/pyrhe_sketch.h`` + a thin torch-tensor wrapper.
 
 PyTorch is plumbing here (device memory, streams); every byte of the sketch is computed by the
-HIP kernels in ``csrc/sketch_engine.hip``.  There is NO CPU fallback: if the shared library is
+HIP kernels in ``csrc/`` (``sketch_engine.hip`` + ``kernels_*.inc``).  There is NO CPU fallback: if the shared library is
 missing or no GPU is present, construction raises.
 """
 from __future__ import annotations
