@@ -182,19 +182,16 @@ def synth_genotypes(n_rows: int, n_samples: int, seed: int, row0: int, device, o
 
 
 def sum_blocks(blocks: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``blocks [jl, ...]`` float32 (contiguous) -> float64 (weighted) sum over the first dimension, by the HIP kernel when
-    the tensor lives on a GPU (``pyrhe_sum_blocks[_weighted]``), by torch on the CPU (multi-process CPU tests of the
-    driver only).  ``weights``: float64 ``[jl]`` on the same device."""
-    if blocks.device.type != "cuda" or blocks.shape[0] == 0 or (blocks[0].numel() % 4):
-        if not blocks.shape[0]:
-            return torch.zeros(blocks.shape[1:], dtype=torch.float64, device=blocks.device)
-        b64 = blocks.to(torch.float64)
-        if weights is not None:
-            b64 = b64 * weights.reshape((-1,) + (1,) * (blocks.dim() - 1))
-        return b64.sum(dim=0)
+    """``blocks [jl, ...]`` float32 (contiguous, on the GPU) -> float64 (weighted) sum over the first dimension by
+    ``pyrhe_sum_blocks[_weighted]``.  ``weights``: float64 ``[jl]`` on the same device."""
+    _require_gpu(blocks.device)
     assert blocks.dtype == torch.float32 and blocks.is_contiguous()
-    out = torch.empty(blocks.shape[1:], dtype=torch.float64, device=blocks.device)
+    out = torch.zeros(blocks.shape[1:], dtype=torch.float64, device=blocks.device)
+    if blocks.shape[0] == 0:
+        return out
     n = blocks[0].numel()
+    if n % 4:
+        raise ValueError("sum_blocks: the block size must be a multiple of 4 elements")
     lib = load_library()
     with torch.cuda.device(blocks.device):
         if weights is None:
@@ -327,6 +324,10 @@ class SketchEngine:
                                                           _ptr(out_norm_dom), 1 if accumulate else 0, _stream_ptr(self.device)),
                    "pyrhe_engine_sketch_block_dom")
         return out_sketch, out_norm, out_sketch_dom, out_norm_dom
+
+    def sum_blocks(self, blocks: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Float64 (weighted) sum over the stored per-block sketches (the reference's ``aggregate``)."""
+        return sum_blocks(blocks, weights)
 
     def set_coding(self, coding: str):
         """How the ``packed`` buffers handed to this engine are coded: ``"plink"`` (default) or ``"value"``."""

@@ -26,7 +26,6 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .engine import sum_blocks
 
 
 # ----------------------------------------------------------------------------- block plan
@@ -538,15 +537,15 @@ class SketchRunner:
             # Block sums as ONE float64 reduction over the stored per-block sketches (the reference adds the blocks one
             # by one in float64, base.py:468-471; any order agrees to 1e-16).  U is linear, so the "fixed" UXXz total is
             # U applied to the total (float32 rounding order differs from per-block application at the 1e-7 level).
-            tot_sk = [sum_blocks(b) for b in self.blocks_sk]
+            tot_sk = [self.eng.sum_blocks(b) for b in self.blocks_sk]
             tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
             tot_skd = tot_nmd = None
             if self.dom:
-                tot_skd = [sum_blocks(b) for b in self.blocks_skd]
+                tot_skd = [self.eng.sum_blocks(b) for b in self.blocks_skd]
                 tot_nmd = [b[:jl].sum(dim=0) for b in self.blocks_nmd]
             if q4:
-                w_sk = [sum_blocks(b, w) for b in self.blocks_sk]
-                w_skd = [sum_blocks(b, w) for b in self.blocks_skd] if self.dom else None
+                w_sk = [self.eng.sum_blocks(b, w) for b in self.blocks_sk]
+                w_skd = [self.eng.sum_blocks(b, w) for b in self.blocks_skd] if self.dom else None
         else:
             # one-slot store: every block is added to the float64 totals (and the (jn - j)-weighted ones of quirk Q4)
             # right after its sketch, in block order

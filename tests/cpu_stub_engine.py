@@ -83,3 +83,12 @@ class CpuStubEngine:
                     out[:, a] -= b.double()
             return out
         return torch.einsum("zal,zbl->zab", mat(x), mat(y))
+
+    def sum_blocks(self, blocks, weights=None):
+        """Oracle-side twin of pyrhe_sum_blocks[_weighted]."""
+        if not blocks.shape[0]:
+            return torch.zeros(blocks.shape[1:], dtype=torch.float64)
+        b64 = blocks.to(torch.float64)
+        if weights is not None:
+            b64 = b64 * weights.reshape((-1,) + (1,) * (blocks.dim() - 1))
+        return b64.sum(dim=0)
