@@ -829,6 +829,10 @@ extern "C" int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, in
     bool fast = period % 32 == 0 && (int64_t)nx * n_batch < (1 << 30);
     for (int a = 0; a < nx && fast; ++a) fast = !x[a].tot && x[a].blk && (((uintptr_t)x[a].blk | (uintptr_t)x[a].mul) & 15) == 0 && x[a].blk_batch_stride % 4 == 0;
     for (int b = 0; b < ny && fast; ++b) fast = y[b].tot && !y[b].blk;
+    // ---- fixed rows against fixed rows (whole-data sketches, covariates, phenotypes), one batch element
+    bool fixed = period % 32 == 0 && n_batch == 1;
+    for (int a = 0; a < nx && fixed; ++a) fixed = x[a].tot && !x[a].blk;
+    for (int b = 0; b < ny && fixed; ++b) fixed = y[b].tot && !y[b].blk;
     static const bool no_fast = getenv("PYRHE_DOTS_GENERIC") && atoi(getenv("PYRHE_DOTS_GENERIC")) != 0;
     // ---- block rows against themselves (x and y are the same block-only rows): the self-Gram path
     bool self = period % 32 == 0 && nx == ny && nx <= 16;
@@ -839,7 +843,9 @@ extern "C" int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, in
     auto table = [&](int a0, int n) {
         BlkRowTable t;
         for (int a = 0; a < kDescMax; ++a)
-            t.r[a] = a < n ? BlkRowDev{x[a0 + a].blk, x[a0 + a].mul, (long long)x[a0 + a].blk_batch_stride} : BlkRowDev{nullptr, nullptr, 0};
+            t.r[a] = a >= n ? BlkRowDev{nullptr, nullptr, 0}
+                     : fixed ? BlkRowDev{reinterpret_cast<const float*>(x[a0 + a].tot), nullptr, 0}
+                             : BlkRowDev{x[a0 + a].blk, x[a0 + a].mul, (long long)x[a0 + a].blk_batch_stride};
         return t;
     };
     if (self && !no_fast) {
@@ -854,11 +860,14 @@ extern "C" int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, in
         if (rc) return rc;
         dim3 grid((unsigned)((n_chunks + 3) / 4), n_sub, tgs);
         blk_self_gram_kernel<<<grid, 256, 0, stream>>>(tab, nx, n_batch, period, chunk, (int)n_chunks, e->dots_partial);
-        blk_self_gram_reduce_kernel<<<(n_batch * nx * nx + 255) / 256, 256, 0, stream>>>(e->dots_partial, n_part, nx, n_batch, out);
+        const int64_t n_out = (int64_t)n_batch * nx * nx;
+        int g_log2 = 0;
+        while (g_log2 < 6 && (n_part >> g_log2) > 8 && (n_out << g_log2) < (1 << 18)) ++g_log2;
+        blk_self_gram_reduce_kernel<<<(unsigned)(((n_out << g_log2) + 255) / 256), 256, 0, stream>>>(e->dots_partial, n_part, nx, n_batch, g_log2, out);
         HIPCHK(hipGetLastError());
         return PYRHE_OK;
     }
-    if (fast && !no_fast) {
+    if ((fast || fixed) && !no_fast) {
         for (int a0 = 0; a0 < nx; a0 += kDescMax) {
             const int nxc = std::min(kDescMax, nx - a0);
             const BlkRowTable tab = table(a0, nxc);
@@ -876,8 +885,12 @@ extern "C" int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, in
                 FixedRows Y;
                 for (int c = 0; c < 16; ++c) Y.p[c] = c < nyt ? y[b0 + c].tot : nullptr;
                 dim3 grid((unsigned)((n_chunks + 3) / 4), n_sub, rgs);
-                blk_fixed_dots_kernel<<<grid, 256, 0, stream>>>(tab, nxc, n_rows, Y, nyt, period, chunk, (int)n_chunks, e->dots_partial);
-                blk_fixed_reduce_kernel<<<(n_rows * 16 + 255) / 256, 256, 0, stream>>>(e->dots_partial, n_part, n_rows, nxc, a0, nx, nyt, b0, ny, out);
+                if (fixed) blk_fixed_dots_kernel<true><<<grid, 256, 0, stream>>>(tab, nxc, n_rows, Y, nyt, period, chunk, (int)n_chunks, e->dots_partial);
+                else blk_fixed_dots_kernel<false><<<grid, 256, 0, stream>>>(tab, nxc, n_rows, Y, nyt, period, chunk, (int)n_chunks, e->dots_partial);
+                int g_log2 = 0;                       // lanes per output: few rows with many partials share the work
+                while (g_log2 < 6 && (n_part >> g_log2) > 8 && ((int64_t)n_rows * 16 << g_log2) < (1 << 18)) ++g_log2;
+                blk_fixed_reduce_kernel<<<(unsigned)((((int64_t)n_rows * 16 << g_log2) + 255) / 256), 256, 0, stream>>>(
+                    e->dots_partial, n_part, n_rows, nxc, a0, nx, nyt, b0, ny, fixed ? 1.0 : -1.0, g_log2, out);
             }
         }
         HIPCHK(hipGetLastError());

@@ -201,7 +201,7 @@ def test_multibin_call_equals_one_call_per_bin(dev, precision, with_fill):
 @pytest.mark.parametrize("nx,ny,n_sub,batch", [(3, 5, 2, 7), (8, 8, 3, 5), (20, 11, 1, 9), (1, 1, 4, 33), (16, 17, 2, 3)])
 def test_loo_dots_paths_vs_float64_reference(dev, nx, ny, n_sub, batch):
     """pyrhe_engine_loo_dots: the register-tiled generic kernel (mixed tot/blk rows), the matrix-core path (block rows
-    x fixed rows) and the self-Gram path (block rows x themselves) against a float64 torch evaluation of the row
+    x fixed rows, fixed rows x fixed rows) and the self-Gram path (block rows x themselves) against a float64 torch evaluation of the row
     definition  tot - blk[z] * mul."""
     from pyrhe_amd import engine
     from pyrhe_amd.engine import Row
@@ -241,6 +241,11 @@ def test_loo_dots_paths_vs_float64_reference(dev, nx, ny, n_sub, batch):
     run(bx, bx)                                      # self Gram (nx <= 16) or generic tiles
     lx = blk_rows(True)
     run(lx, lx)                                      # generic: leave-one-out Gram
+    # fixed rows x fixed rows, one batch element: the float64-row matrix-core path
+    fx = [(Row(totx[a]), None) for a in range(nx)]
+    got = eng.loo_dots([r for r, _ in fx], [r for r, _ in fixed], period, n_sub, 1).cpu()
+    ref = (totx @ toty.T).cpu()[None]
+    assert (got - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
     eng.close()
 
 
