@@ -210,7 +210,7 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     const size_t oWscale = carve((size_t)kMaxSeg * kSegCols * sizeof(float));
     // every segment pads its tail to a 32-entry K block (64 for the int8 GEMM 2)
     const size_t oWfrag = carve((S / 32 + kMaxSeg) * e->parts * kMaxTiles * 64 * sizeof(half8));
-    const size_t oRows = carve((S + 64 + 32 * kMaxSeg) * sizeof(int32_t));
+    const size_t oRows = carve((S + 64 + 64 * kMaxSeg) * sizeof(int32_t));
     e->ws_bytes = off;
     for (int i = 0; i < 2; ++i) {
         uint8_t* base = nullptr;
@@ -424,6 +424,9 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     const int64_t sk_stride = (int64_t)e->n_sketch * e->n_pad;
     const float pscale = e->exact ? 1.0f : 16777216.0f;
     const int kstep = g2i8 ? 64 : 32;
+    // limb-packed int8 GEMM 2 (see gemm2_i8p_kernel): segment mode, <= 10 sketch columns, additive view
+    static const bool g2p_off = getenv("PYRHE_G2_PACKED") && atoi(getenv("PYRHE_G2_PACKED")) == 0;
+    const bool g2p_ok = !g2p_off && e->i8 && e->n_sketch >= 1 && e->n_sketch <= kI8pCols && !dom && !g2i8;
 
     if (dom && !e->dom_ws) {
         const size_t S = (size_t)e->sub_snps, nc = 16 * kMaxTiles;
@@ -497,7 +500,11 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             ProfScope ps(e, stream, 1);
             const int64_t threads = (int64_t)n_kb * e->parts * e->nto * 64;
             const unsigned grid = (unsigned)std::max<int64_t>((threads + 255) / 256, (int64_t)tab.nseg * e->n_norm);
-            if (g2i8) {
+            if (g2p_ok && segmode && gv == 0) {
+                const unsigned gridp = (unsigned)std::max<int64_t>(((int64_t)n_kb * 64 + 255) / 256, (int64_t)tab.nseg * e->n_norm);
+                mid2_i8p_kernel<<<gridp, 256, 0, stream>>>(Wsrc, coef, e->n_sketch, wmaxp, (int4v*)e->wfrag, e->corr, e->wscale, rows, e->rows32,
+                                                           nsrc, ndst, e->n_norm, tab);
+            } else if (g2i8) {
                 const int64_t th = (int64_t)n_kb * 3 * 64;
                 mid2_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, wmaxp, (int4v*)e->wfrag, e->corr, e->wscale);
                 pad_rows_kernel<<<(n_kb * 64 + 255) / 256, 256, 0, stream>>>(rows, n, n_kb * 64, e->rows32);
@@ -550,7 +557,14 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         }
         ProfScope ps(e, sB2, 2);
 #define G2(NTO_, PARTS_, IW_, EX_, GV_) launch_gemm2<NTO_, PARTS_, IW_, EX_, GV_>(e, packed, n_kb, kbps, splits, fill, outp, mode, partial, sB2, gtab)
-        if (g2i8) {
+        if (g2p_ok && segmode && gv == 0) {
+            dim3 grid((unsigned)((e->n_pad + 1023) / 1024), tab.nseg);
+            const size_t lds = (size_t)kbps * 128;
+#define L2P(MISS_, VC_) gemm2_i8p_kernel<MISS_, VC_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, tab)
+            if (e->vc) { if (fill) L2P(true, true); else L2P(false, true); }
+            else { if (fill) L2P(true, false); else L2P(false, false); }
+#undef L2P
+        } else if (g2i8) {
             dim3 grid((unsigned)((e->n_pad + 1023) / 1024), splits);
             const size_t lds = (size_t)kbps * 256;
 #define L2I(MISS_, VC_) gemm2_i8_kernel<MISS_, VC_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, mode, partial)
@@ -600,7 +614,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 tab.acc[g] = (accumulate || touched[b]) ? 1 : 0;
                 touched[b] = 1;
                 n += take;
-                kb += (take + 31) / 32;
+                kb += g2p_ok ? 2 * ((take + 63) / 64) : (take + 31) / 32;     // the packed int8 GEMM 2 walks 64-entry K blocks
                 pos += take;
             }
             tab.start[tab.nseg] = n;
