@@ -189,6 +189,12 @@ def main():
     g1, g2 = prof["gemm1_ms"], prof["gemm2_ms"]
     dom = "gemm2_kernel" if g2 >= g1 else "gemm1_kernel"
     dom_ms = max(g1, g2)
+    # which kernels ran (pyrhe_amd/csrc/sketch_engine.hip): int8 GEMM 1 under i8x3 / i8f16; the limb-packed int8 GEMM 2
+    # under i8x3 with <= 10 sketch columns, the fp16 GEMM 2 otherwise
+    g1_name = "gemm1_i8_kernel" if args.precision in ("i8x3", "i8f16") else "gemm1_kernel"
+    g2_packed = args.precision == "i8x3" and 1 <= engine.n_sketch <= 10 and os.environ.get("PYRHE_G2_PACKED", "1") != "0"
+    g2_name = "gemm2_i8p_kernel" if g2_packed else "gemm2_kernel"
+    dom_name = g2_name if dom == "gemm2_kernel" else g1_name
     bytes_per_launch = local_snps * row_bytes / launches                    # algorithmic bytes: ceil(N/4) per SNP
     achieved = bytes_per_launch / (dom_ms / launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md): the measured
@@ -198,27 +204,30 @@ def main():
     try:
         with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as fh:
             tj = json.load(fh)
-        key = {"gemm1_kernel": "gemm1_i8_kernel" if args.precision == "i8x3" else "gemm1_kernel_f16",
-               "gemm2_kernel": "gemm2_kernel_f16" if args.precision == "f16" else "gemm2_kernel_f16x2"}[dom]
+        key = {"gemm1_kernel": "gemm1_i8_kernel" if g1_name == "gemm1_i8_kernel" else "gemm1_kernel_f16",
+               "gemm2_kernel": "gemm2_i8p_kernel" if g2_packed else
+                               ("gemm2_kernel_f16" if args.precision in ("f16", "i8f16") else "gemm2_kernel_f16x2")}[dom]
         if N == tj["n_indv"] and M // jn == tj["block_snps"] and args.n_bin == 1:
             traffic = int(tj["kernels"][key]["bytes_per_algorithmic_byte"] * bytes_per_launch)
     except Exception:
         traffic = None
     # matrix-core work of the dominant kernel as issued (16-column tiles, all limbs / parts), beside the byte roofline:
-    # GEMM 2 is bound by instruction issue (matrix + unpack instructions do not overlap), not by HBM
+    # (the fp16 GEMM 2 is bound by instruction issue; the packed int8 GEMM 2 and GEMM 1 by HBM)
     n_pad = engine.n_pad
     tiles_in = (engine.n_sketch + engine.n_norm + 1 + 15) // 16              # + the ones column
     tiles_out = max(1, (engine.n_sketch + 15) // 16)
     rows_per_launch = local_snps / launches
-    if dom == "gemm2_kernel":
-        parts = 1 if args.precision in ("f16", "f16e") else 2
+    if dom == "gemm2_kernel" and g2_packed:
+        mfma_ops, mfma_peak = rows_per_launch * 2.0 * n_pad * 16 * 2, 5000.0    # two packed tiles of (digit, column) rows; int8 dense TOP/s
+    elif dom == "gemm2_kernel":
+        parts = 1 if args.precision in ("f16", "f16e", "i8f16") else 2
         mfma_ops, mfma_peak = rows_per_launch * 2.0 * n_pad * 16 * tiles_out * parts, 2500.0       # fp16 dense TFLOP/s
     else:
-        parts = {"i8x3": 3, "f16x2": 2}.get(args.precision, 1)
+        parts = {"i8x3": 3, "i8f16": 3, "f16x2": 2}.get(args.precision, 1)
         mfma_ops = rows_per_launch * 2.0 * n_pad * 16 * tiles_in * parts
-        mfma_peak = 5000.0 if args.precision == "i8x3" else 2500.0                                 # int8 dense TOP/s
+        mfma_peak = 5000.0 if g1_name == "gemm1_i8_kernel" else 2500.0                             # int8 dense TOP/s
     mfma_tops = mfma_ops / (dom_ms / launches * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "mfma_tops_issued": round(mfma_tops, 1), "mfma_frac": round(mfma_tops / mfma_peak, 4),
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(dom_ms / launches, 4),
@@ -229,7 +238,7 @@ def main():
     out = {"metric": "SNPs/sec through streaming trace sketch (N=500k, k=10, jn=100)", "value": value, "unit": "SNPs/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": {"f16x2": "f16x2", "i8x3": "i8x3+f16x2", "f16": "f16", "f16e": "f16", "i8f16": "i8x3+f16"}[args.precision], "data": "synthetic",
+           "dtype": {"f16x2": "f16x2", "i8x3": "i8x3" if g2_packed else "i8x3+f16x2", "f16": "f16", "f16e": "f16", "i8f16": "i8x3+f16"}[args.precision], "data": "synthetic",
            "config": {"workload": f"synthetic N={N} M={M} {args.n_bin}-bin "
                                   + (f"StreamingGENIE {args.genie} (1 environment)" if args.genie else "StreamingRHE")
                                   + f" sketch pass, k={k} jn={jn}" + (f", {args.n_cov} covariates" if args.n_cov else ""),

@@ -589,7 +589,9 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     };
 
     // ---- several bins, additive sketch only: GEMM 1 once per chunk of the concatenated lists, per-bin work by segment
-    const bool segflow = nbin > 1 && !dom && !g2i8;
+    // (a single list takes this flow too when the packed int8 GEMM 2 applies and the sample range alone fills the chip;
+    // small cohorts keep the per-list flow, whose GEMM 2 can split K over workgroups)
+    const bool segflow = !dom && !g2i8 && (nbin > 1 || (g2p_ok && e->n_pad >= 192 * 1024));
     if (segflow) {
         std::vector<char> touched(nbin, 0);
         for (int b = 0; b < nbin; ++b)

@@ -15,12 +15,24 @@ def grab(section, kern, counter):
     return int(m.group(1)), float(m.group(2))
 
 
-names = {"gemm1_i8_kernel": "void gemm1_i8_kernel<1, false, 0, true>", "gemm2_kernel_f16x2": "_Z12gemm2_kernelILi1ELi2ELi1ELb1ELb0ELi0",
+names = {"gemm1_i8_kernel": "void gemm1_i8_kernel<1, false, 0, true>", "gemm2_i8p_kernel": "void gemm2_i8p_kernel<false, true>",
+         "gemm2_kernel_f16x2": "_Z12gemm2_kernelILi1ELi2ELi1ELb1ELb0ELi0",
          "gemm1_kernel_f16": "_Z12gemm1_kernelILi1ELi1ELb0ELb0ELi0ELb1", "gemm2_kernel_f16": "_Z12gemm2_kernelILi1ELi1ELi2ELb0ELb0ELi0"}
 out = {"_comment": __doc__.strip(), "n_indv": N, "block_snps": 10000, "kernels": {}}
+try:
+    prev = json.load(open("profiles/r01_traffic.json"))["kernels"]
+except Exception:
+    prev = {}
 for k, n in names.items():
-    nf, f = grab("pmc_fetch", n, "FETCH_SIZE")
-    nw, w = grab("pmc_write", n, "WRITE_SIZE")
+    try:
+        nf, f = grab("pmc_fetch", n, "FETCH_SIZE")
+        nw, w = grab("pmc_write", n, "WRITE_SIZE")
+    except Exception:
+        # not launched by the default bench command any more (the fp16 hi+lo GEMM 2 is the fallback for > 10 sketch
+        # columns): keep the figure of the earlier pass of this round
+        if k in prev:
+            out["kernels"][k] = dict(prev[k], carried_over="earlier PMC pass of this round")
+        continue
     total = 2 * f * 1024 * nf + w * 1024 * nw
     out["kernels"][k] = {"launches": nf, "fetch_size_mean": f, "write_size_mean": w, "bytes_per_algorithmic_byte": round(total / alg, 4)}
 json.dump(out, open("profiles/r01_traffic.json", "w"), indent=2)
