@@ -190,9 +190,9 @@ def main():
     dom = "gemm2_kernel" if g2 >= g1 else "gemm1_kernel"
     dom_ms = max(g1, g2)
     # which kernels ran (pyrhe_amd/csrc/sketch_engine.hip): int8 GEMM 1 under i8x3 / i8f16; the limb-packed int8 GEMM 2
-    # under i8x3 with <= 10 sketch columns, the fp16 GEMM 2 otherwise
+    # under i8x3 with <= 20 sketch columns, the fp16 GEMM 2 otherwise
     g1_name = "gemm1_i8_kernel" if args.precision in ("i8x3", "i8f16") else "gemm1_kernel"
-    g2_packed = args.precision == "i8x3" and 1 <= engine.n_sketch <= 10 and os.environ.get("PYRHE_G2_PACKED", "1") != "0"
+    g2_packed = args.precision == "i8x3" and 1 <= engine.n_sketch <= 20 and os.environ.get("PYRHE_G2_PACKED", "1") != "0"
     g2_name = "gemm2_i8p_kernel" if g2_packed else "gemm2_kernel"
     dom_name = g2_name if dom == "gemm2_kernel" else g1_name
     bytes_per_launch = local_snps * row_bytes / launches                    # algorithmic bytes: ceil(N/4) per SNP
@@ -218,7 +218,8 @@ def main():
     tiles_out = max(1, (engine.n_sketch + 15) // 16)
     rows_per_launch = local_snps / launches
     if dom == "gemm2_kernel" and g2_packed:
-        mfma_ops, mfma_peak = rows_per_launch * 2.0 * n_pad * 16 * 2, 5000.0    # two packed tiles of (digit, column) rows; int8 dense TOP/s
+        mfma_ops = rows_per_launch * 2.0 * n_pad * 16 * (2 if engine.n_sketch <= 10 else 4)   # packed tiles of (digit, column) rows
+        mfma_peak = 5000.0                                                                     # int8 dense TOP/s
     elif dom == "gemm2_kernel":
         parts = 1 if args.precision in ("f16", "f16e", "i8f16") else 2
         mfma_ops, mfma_peak = rows_per_launch * 2.0 * n_pad * 16 * tiles_out * parts, 2500.0       # fp16 dense TFLOP/s

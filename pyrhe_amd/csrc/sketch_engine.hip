@@ -426,7 +426,8 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     const int kstep = g2i8 ? 64 : 32;
     // limb-packed int8 GEMM 2 (see gemm2_i8p_kernel): segment mode, <= 10 sketch columns, additive view
     static const bool g2p_off = getenv("PYRHE_G2_PACKED") && atoi(getenv("PYRHE_G2_PACKED")) == 0;
-    const bool g2p_ok = !g2p_off && e->i8 && e->n_sketch >= 1 && e->n_sketch <= kI8pCols && !dom && !g2i8;
+    const bool g2p_ok = !g2p_off && e->i8 && e->parts == 2 && e->n_sketch >= 1 && e->n_sketch <= 2 * kI8pCols && !dom && !g2i8;
+    const int g2p_ng = e->n_sketch <= kI8pCols ? 1 : 2;        // column groups of 10 = pairs of A tiles
 
     if (dom && !e->dom_ws) {
         const size_t S = (size_t)e->sub_snps, nc = 16 * kMaxTiles;
@@ -501,8 +502,8 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             const int64_t threads = (int64_t)n_kb * e->parts * e->nto * 64;
             const unsigned grid = (unsigned)std::max<int64_t>((threads + 255) / 256, (int64_t)tab.nseg * e->n_norm);
             if (g2p_ok && segmode && gv == 0) {
-                const unsigned gridp = (unsigned)std::max<int64_t>(((int64_t)n_kb * 64 + 255) / 256, (int64_t)tab.nseg * e->n_norm);
-                mid2_i8p_kernel<<<gridp, 256, 0, stream>>>(Wsrc, coef, e->n_sketch, wmaxp, (int4v*)e->wfrag, e->corr, e->wscale, rows, e->rows32,
+                const unsigned gridp = (unsigned)std::max<int64_t>(((int64_t)n_kb * 64 * g2p_ng + 255) / 256, (int64_t)tab.nseg * e->n_norm);
+                mid2_i8p_kernel<<<gridp, 256, 0, stream>>>(Wsrc, coef, e->n_sketch, 2 * g2p_ng, wmaxp, (int4v*)e->wfrag, e->corr, e->wscale, rows, e->rows32,
                                                            nsrc, ndst, e->n_norm, tab);
             } else if (g2i8) {
                 const int64_t th = (int64_t)n_kb * 3 * 64;
@@ -558,11 +559,13 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         ProfScope ps(e, sB2, 2);
 #define G2(NTO_, PARTS_, IW_, EX_, GV_) launch_gemm2<NTO_, PARTS_, IW_, EX_, GV_>(e, packed, n_kb, kbps, splits, fill, outp, mode, partial, sB2, gtab)
         if (g2p_ok && segmode && gv == 0) {
-            dim3 grid((unsigned)((e->n_pad + 1023) / 1024), tab.nseg);
+            dim3 grid((unsigned)((e->n_pad + 1023) / 1024 * g2p_ng), tab.nseg);       // NG = 2: a workgroup covers 512 samples
             const size_t lds = (size_t)kbps * 128;
-#define L2P(MISS_, VC_) gemm2_i8p_kernel<MISS_, VC_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, tab)
-            if (e->vc) { if (fill) L2P(true, true); else L2P(false, true); }
-            else { if (fill) L2P(true, false); else L2P(false, false); }
+#define L2P(NG_, MISS_, VC_) gemm2_i8p_kernel<NG_, MISS_, VC_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, tab)
+#define L2Q(NG_) do { if (e->vc) { if (fill) L2P(NG_, true, true); else L2P(NG_, false, true); } \
+                      else { if (fill) L2P(NG_, true, false); else L2P(NG_, false, false); } } while (0)
+            if (g2p_ng == 1) L2Q(1); else L2Q(2);
+#undef L2Q
 #undef L2P
         } else if (g2i8) {
             dim3 grid((unsigned)((e->n_pad + 1023) / 1024), splits);
