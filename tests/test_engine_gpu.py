@@ -151,14 +151,19 @@ def test_block_stats_exact(dev):
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["i8x3", "f16x2", "f16"])
+@pytest.mark.parametrize("precision,k,coding", [("i8x3", 10, "plink"), ("i8x3", 10, "value"), ("i8x3", 20, "plink"),
+                                                ("i8x3", 20, "value"), ("i8x3", 7, "value"), ("i8x3", 13, "plink"),
+                                                ("f16x2", 10, "plink"), ("f16", 10, "plink")])
 @pytest.mark.parametrize("with_fill", [False, True])
-def test_multibin_call_equals_one_call_per_bin(dev, precision, with_fill):
+def test_multibin_call_equals_one_call_per_bin(dev, precision, k, coding, with_fill):
     """Several bins in one call take the segmented flow (one GEMM 1 over the concatenated lists, per-bin scales,
     corrections, norms and GEMM 2 ranges by segment); one call per bin takes the single-list flow.  Same results,
-    including: overlapping bins, an empty bin, bins shorter than a K block, lists cut by sub_snps chunks, accumulate."""
+    including: overlapping bins, an empty bin, bins shorter than a K block, lists cut by sub_snps chunks, accumulate.
+    Under i8x3 the segmented flow runs the limb-packed int8 GEMM 2 (two A tiles up to 10 sketch columns, four up to 20,
+    both genotype codings, with and without fill values) and the single-list flow the fp16 hi+lo GEMM 2: two independent
+    kernels, one answer."""
     from pyrhe_amd import engine
-    n, m, k = 5000, 900, 10
+    n, m = 5000, 900
     rng = np.random.default_rng(5)
     packed = engine.synth_genotypes(m, n, 77, 0, dev)
     fill = None
@@ -171,7 +176,10 @@ def test_multibin_call_equals_one_call_per_bin(dev, precision, with_fill):
     lists = [np.sort(rng.choice(m, sz, replace=False)).astype(np.int32) for sz in (311, 0, 17, 450, 64, 129)]
     offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
     entries = torch.from_numpy(np.concatenate(lists)).to(dev)
+    if coding == "value":
+        packed = engine.recode_rows(packed, "value")
     eng = engine.SketchEngine(n, n, max_entries=m, precision=precision, device=dev, sub_snps=256)
+    eng.set_coding(coding)
     keep = eng.keep_vector([])
     Z = torch.zeros((k, eng.n_pad), device=dev)
     Z[:, :n] = torch.from_numpy(rng.standard_normal((k, n)).astype(np.float32)).to(dev)
