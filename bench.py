@@ -224,8 +224,11 @@ def main():
         parts = 1 if args.precision in ("f16", "f16e", "i8f16") else 2
         mfma_ops, mfma_peak = rows_per_launch * 2.0 * n_pad * 16 * tiles_out * parts, 2500.0       # fp16 dense TFLOP/s
     else:
-        parts = {"i8x3": 3, "i8f16": 3, "f16x2": 2}.get(args.precision, 1)
-        mfma_ops = rows_per_launch * 2.0 * n_pad * 16 * tiles_in * parts
+        if g1_name == "gemm1_i8_kernel":       # packed (digit, column) rows: 3 per user column + the ones column
+            g1_tiles = (3 * (engine.n_sketch + engine.n_norm) + 1 + 15) // 16
+        else:
+            g1_tiles = tiles_in * (2 if args.precision == "f16x2" else 1)
+        mfma_ops = rows_per_launch * 2.0 * n_pad * 16 * g1_tiles
         mfma_peak = 5000.0 if g1_name == "gemm1_i8_kernel" else 2500.0                             # int8 dense TOP/s
     mfma_tops = mfma_ops / (dom_ms / launches * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -88,6 +88,35 @@ __device__ __forceinline__ float pow2_scale(float maxabs) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// int8 digits.  Balanced radix 256: x = a1 + a2 / 256 + a3 / 65536 with every digit in [-128, 127] and |x| <= 126 -- all
+// 24 bits of a float32.  Every step is exact in float32: x - rint(x), the multiplications by 256, the carries.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float i8p_scale(float maxabs) {
+    if (!(maxabs > 0.0f) || !isfinite(maxabs)) return 1.0f;
+    return 126.0f / maxabs;
+}
+__device__ __forceinline__ void i8p_digits(float x, float& a1, float& a2, float& a3) {
+    a1 = rintf(x);
+    const float r1 = (x - a1) * 256.0f;               // [-128, 128]
+    a2 = rintf(r1);
+    a3 = rintf((r1 - a2) * 256.0f);                   // [-128, 128]
+    if (a3 > 127.0f) { a3 -= 256.0f; a2 += 1.0f; }
+    if (a2 > 127.0f) { a2 -= 256.0f; a1 += 1.0f; }     // |a1| <= 127 since |x| <= 126
+}
+// Rows ("slots") of the int8 GEMM 1's B operand: the (digit, column) pairs packed densely into 16-row tiles instead of
+// one tile set per digit.  `ones` user columns carry three digits, the ones column (index `ones`, values 0 / 1) one:
+// slots 0..ones = digit 0 of every column, then digit 1 and digit 2 of the user columns; 3 * ones + 1 slots in all
+// (k = 10 probes + phenotype: 34 -> 3 tiles; with covariates or GxE, 21 columns: 64 -> 4 tiles instead of 6).
+__device__ __host__ __forceinline__ int i8_slot(int digit, int c, int ones) {
+    return digit == 0 ? c : (digit == 1 ? ones + 1 + c : 2 * ones + 1 + c);
+}
+__device__ __forceinline__ double i8_value(const int* __restrict__ Prow, int c, int ones) {
+    double v = (double)Prow[c];
+    if (c < ones) v += (double)Prow[ones + 1 + c] * (1.0 / 256.0) + (double)Prow[2 * ones + 1 + c] * (1.0 / 65536.0);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Segment table of one chunk of entries, passed to the kernels BY VALUE (kernel argument: no upload, no sync).
 // A chunk is a run of the caller's concatenated per-bin entry lists; segment g = the part of bin `bin[g]` inside the
 // chunk = chunk entries start[g] .. start[g+1]-1.  GEMM 1 does not care about bins (X^T R is per SNP) and runs once

@@ -82,7 +82,7 @@ struct pyrhe_engine {
     bool exact = false;   // exact (normal-number) genotype unpack instead of the 1-op subnormal unpack
     bool i8 = false;      // GEMM 1 on int8 limbs (precision i8x3); GEMM 2 then runs the hi+lo fp16 form
     bool vc = false;      // the caller's packed buffers hold the 2-bit VALUE code (pyrhe_recode_rows), not PLINK codes
-    int n_sketch = 0, n_norm = 0, n_user = 0, ntl = 0, nto = 0;
+    int n_sketch = 0, n_norm = 0, n_user = 0, ntl = 0, nto = 0, nt8 = 0;
     bool rhs_set = false;
     // device buffers
     half8* rfrag = nullptr;
@@ -299,6 +299,7 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
     e->n_norm = nn;
     e->n_user = n_cols;
     e->ntl = (n_cols + 1 + 15) / 16;
+    e->nt8 = (3 * n_cols + 1 + 15) / 16;          // int8 GEMM 1: tiles of packed (digit, column) rows, see i8_slot()
     e->nto = ns ? (ns + 15) / 16 : 1;
     if (e->ntl > kMaxTiles) return fail(PYRHE_EINVAL, "too many columns");
     HIPCHK(hipMemcpyAsync(e->keep, keep, e->n_pad * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -312,8 +313,8 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
         const int64_t threads = (e->n_pad / 256) * 8 * e->parts * e->ntl * 64;
         const unsigned grid = (unsigned)((threads + 255) / 256);
         if (e->i8) {
-            const int64_t th = (e->n_pad / 256) * 4 * 3 * e->ntl * 64;
-            prep_rimg_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale,
+            const int64_t th = (e->n_pad / 256) * 4 * e->nt8 * 64;
+            prep_rimg_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->nt8, e->colmax, e->rscale,
                                                                               (int4v*)e->rfrag, e->csum);
         } else if (e->parts == 2)
             prep_rfrag_kernel<2, true><<<grid, 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale, e->rfrag, e->csum);
@@ -420,7 +421,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     hipStream_t stream = piped ? e->sA : caller;
     hipStream_t sB2 = piped ? e->sB : caller;
     const int n_chunks = (int)(e->pitch / 64);
-    const int ncol_p = 16 * e->ntl;
+    const int ncol_p = 16 * (e->i8 ? e->nt8 : e->ntl);       // values (fp16 form) / packed int32 slots (int8 form) per entry of P
     const int64_t sk_stride = (int64_t)e->n_sketch * e->n_pad;
     const float pscale = e->exact ? 1.0f : 16777216.0f;
     const int kstep = g2i8 ? 64 : 32;
@@ -453,7 +454,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     // ---- GEMM 1 of one entry list, genotype view gv, into Pbuf (zeroed by the caller)
     auto run_gemm1 = [&](int gv, const int32_t* rows, int n, float* Pbuf) {
         const int gx = (n + 255) / 256;
-        const int g1_ch = (e->i8 && e->ntl > 1) ? 1 : 2;  // 256-sample chunks per step (see gemm1_i8_kernel)
+        const int g1_ch = (e->i8 && e->nt8 > 3) ? 1 : 2;  // 256-sample chunks per step (see gemm1_i8_kernel)
         const int n_steps = n_chunks / g1_ch;             // pitch is a multiple of 256 B = 4 chunks
         static const int g1_wgs = getenv("PYRHE_G1_WGS") ? atoi(getenv("PYRHE_G1_WGS")) : 1536;   // target workgroups per launch
         int splits = (g1_wgs + gx - 1) / gx;
@@ -467,11 +468,20 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         dim3 grid(gx, splits);
         const int ua = splits > 1;
         if (e->i8) {
-            const size_t lds = (size_t)2 * g1_ch * 12 * e->ntl * 1024;
-#define G1I(NTL_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NTL_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua); \
-                                   else gemm1_i8_kernel<NTL_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua); } while (0)
-            if (gv == 0) { if (e->ntl == 1) { if (fill) G1I(1, true, 0); else G1I(1, false, 0); } else { if (fill) G1I(2, true, 0); else G1I(2, false, 0); } }
-            else         { if (e->ntl == 1) { if (fill) G1I(1, true, 1); else G1I(1, false, 1); } else { if (fill) G1I(2, true, 1); else G1I(2, false, 1); } }
+            const size_t lds = (size_t)2 * g1_ch * 4 * e->nt8 * 1024;
+#define G1I(NT_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua); \
+                                  else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua); } while (0)
+#define G1J(NT_) do { if (gv == 0) { if (fill) G1I(NT_, true, 0); else G1I(NT_, false, 0); } \
+                      else { if (fill) G1I(NT_, true, 1); else G1I(NT_, false, 1); } } while (0)
+            switch (e->nt8) {
+                case 1: G1J(1); break;
+                case 2: G1J(2); break;
+                case 3: G1J(3); break;
+                case 4: G1J(4); break;
+                case 5: G1J(5); break;
+                default: G1J(6); break;
+            }
+#undef G1J
 #undef G1I
         } else {
 #define G1(NTL_, PARTS_, EX_, GV_) launch_gemm1<NTL_, PARTS_, EX_, GV_>(e, packed, rows, n, fill, n_steps, cps, splits, stream)
