@@ -40,19 +40,23 @@ extern "C" {
 #define PYRHE_ENOMEM (-2)   /* workspace too small / allocation failed */
 #define PYRHE_ESTATE (-3)   /* call order (e.g. sketch before set_rhs) */
 
-/* precision modes: how the float32 operands R and W = D V are fed to the fp16 matrix cores */
+/* precision modes: how the float32 operands R and W = D V are fed to the matrix cores */
 #define PYRHE_PREC_F16 0    /* one fp16 rounding (11 significant bits), 1 MFMA pass            */
 #define PYRHE_PREC_F16X2 1  /* hi + lo fp16 split (~22 significant bits), 2 MFMA passes        */
 #define PYRHE_PREC_F16_EXACT 2 /* one fp16 rounding, genotypes unpacked to normal fp16 numbers (3 VALU ops per
                                   register pair instead of the 1-op subnormal unpack of PYRHE_PREC_F16)        */
 
-#define PYRHE_PREC_I8X3 3   /* GEMM 1 on three int8 limbs (22 bits of the column maximum, exact int32 accumulation,
-                               2x K per MFMA); GEMM 2 as PYRHE_PREC_F16X2.  Parity-safe like F16X2, less work.      */
+#define PYRHE_PREC_I8X3 3   /* both contractions on the int8 matrix cores: every operand column as three balanced radix-256
+                               int8 digits (all 24 bits of the float32), exact int32 accumulation, 2x K per MFMA, the
+                               (digit, column) pairs packed densely into 16-row tiles.  GEMM 2 takes this form for up to
+                               20 sketch columns per call of several lists (or one list of a large cohort); otherwise it
+                               runs as PYRHE_PREC_F16X2.  The parity-safe default.                                      */
 
-#define PYRHE_PREC_I8X3_F16 4 /* GEMM 1 as I8X3, GEMM 2 with ONE fp16 rounding of W (as PYRHE_PREC_F16): 20 % faster than
-                                 I8X3; measured vs I8X3 (M = 200k, jn = 100): sigma^2 3e-5 / 6e-6 / 2e-6 / 3e-7 and SE
-                                 5e-5 / 1.3e-5 / 9e-6 / 9e-6 at N = 5k / 20k / 100k / 500k -- the SE error does not shrink
-                                 with N (it is set by the SNPs per block), so this mode is NOT the parity-safe default */
+#define PYRHE_PREC_I8X3_F16 4 /* GEMM 1 as I8X3, GEMM 2 with ONE fp16 rounding of W (as PYRHE_PREC_F16).  Measured vs I8X3
+                                 (M = 200k, jn = 100): sigma^2 3e-5 / 6e-6 / 2e-6 / 3e-7 and SE 5e-5 / 1.3e-5 / 9e-6 / 9e-6
+                                 at N = 5k / 20k / 100k / 500k -- the SE error does not shrink with N (it is set by the
+                                 SNPs per block), so this mode is NOT parity-safe; since the int8 GEMM 2 it is not faster
+                                 than I8X3 either (kept for the precision experiments of DESIGN.md 3.1)                  */
 
 /* column roles for pyrhe_engine_set_rhs */
 #define PYRHE_COL_SKETCH 1  /* gets both contractions: out[:, col] = X (X^T r)   (a7/a9 in SURVEY 8a) */
