@@ -631,6 +631,10 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 n += take;
                 kb += g2p_ok ? 2 * ((take + 63) / 64) : (take + 31) / 32;     // the packed int8 GEMM 2 walks 64-entry K blocks
                 pos += take;
+                // A list cut here (longer than a segment may be, or than the chunk has room for) continues in the NEXT
+                // chunk: its pieces add into the same output slab and norm slot, and only launches are ordered -- the
+                // segments of one launch run concurrently.
+                if (pos < offsets_host[b + 1]) break;
             }
             tab.start[tab.nseg] = n;
             tab.kb0[tab.nseg] = kb;

@@ -377,3 +377,36 @@ def test_random_shapes_against_dense_float64(dev, seed):
         assert np.allclose(nm[b], refn, rtol=2e-5)
         assert not sk[b][:, np.setdiff1d(np.arange(eng.n_pad), keep_idx)].any()
     eng.close()
+
+
+@pytest.mark.parametrize("precision", ["i8x3", "f16x2"])
+def test_lists_longer_than_a_segment(dev, precision):
+    """Bins with more entries than one segment holds (16384: GEMM 2 keeps a segment's row list in LDS) are cut into pieces
+    that add into the same output slab.  The pieces must never share a launch (segments of a launch run concurrently):
+    same results as one call per bin, and the same bits on every run."""
+    from pyrhe_amd import engine
+    n, m, k = 2000, 40000, 10
+    rng = np.random.default_rng(11)
+    packed = engine.synth_genotypes(m, n, 5, 0, dev)
+    lists = [np.sort(rng.choice(m, sz, replace=False)).astype(np.int32) for sz in (20000, 300, 18000, 33000)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+    entries = torch.from_numpy(np.concatenate(lists)).to(dev)
+    eng = engine.SketchEngine(n, n, max_entries=m, precision=precision, device=dev, sub_snps=65536)   # chunks of several segments
+    keep = eng.keep_vector([])
+    Z = torch.zeros((k, eng.n_pad), device=dev)
+    Z[:, :n] = torch.from_numpy(rng.standard_normal((k, n)).astype(np.float32)).to(dev)
+    y = torch.zeros((1, eng.n_pad), device=dev)
+    y[:, :n] = torch.from_numpy(rng.standard_normal((1, n)).astype(np.float32)).to(dev)
+    eng.set_rhs(Z, y, keep)
+    sk, nm, _ = eng.sketch_block(packed, entries, offs)
+    sk, nm = sk.clone(), nm.clone()
+    sk_b, nm_b, _ = eng.sketch_block(packed, entries, offs)
+    torch.cuda.synchronize()
+    assert torch.equal(sk, sk_b) and torch.equal(nm, nm_b)
+    for b, lst in enumerate(lists):
+        s1, n1, _ = eng.sketch_block(packed, torch.from_numpy(lst).to(dev), [0, len(lst)])
+        torch.cuda.synchronize()
+        scale = s1.abs().max().item()
+        assert (sk[b] - s1[0]).abs().max().item() <= 2e-6 * scale, b
+        assert torch.allclose(nm[b], n1[0], rtol=2e-6, atol=0), b
+    eng.close()
