@@ -99,7 +99,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from pyrhe_amd import engine as eng_mod
-    from pyrhe_amd.streaming import BlockPlan, SketchRunner, engine_capacity, shard_ranges
+    from pyrhe_amd.streaming import n_engines_needed, BlockPlan, SketchRunner, engine_capacity, shard_ranges
     from pyrhe_amd import estimate as est
 
     N, M, jn, k = args.n_indv, args.n_snp, args.jn, args.k
@@ -144,14 +144,15 @@ def main():
     if args.n_cov > 0:
         cov = np.concatenate([np.ones((N, 1)), np.random.default_rng(2).normal(size=(N, args.n_cov - 1))], axis=1)
     env = None
-    engines = engine
     if args.genie:
         env = np.random.default_rng(3).integers(0, 2, size=N).astype(np.float64)     # Bernoulli(0.5)
-        n_cols = (2 if cov is None else 4) * k + 2
-        if n_cols > 30:                               # [Z, UZ | y] and [e.Z, e.UZ | e.y] on two engines
-            engines = [engine, eng_mod.SketchEngine(N, N, max_entries=engine_capacity(plan), precision=args.precision, device=dev,
-                                                    sub_snps=args.sub_snps or engine_capacity(plan))]
-            engines[1].set_coding(coding)
+    # one engine per pass over the genotypes: the column groups (Z, UZ, e.Z, e.UZ of k columns each) that do not fit one
+    # engine's 30 right-hand columns go to further engines (k = 10: one, or two for GxE + covariates)
+    engines = [engine]
+    for _ in range(n_engines_needed(k, cov is not None, bool(args.genie)) - 1):
+        engines.append(eng_mod.SketchEngine(N, N, max_entries=engine_capacity(plan), precision=args.precision, device=dev,
+                                            sub_snps=args.sub_snps or engine_capacity(plan)))
+        engines[-1].set_coding(coding)
     runner = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, cov=cov, env=env,
                           genie_model=args.genie, seed=0, streaming=True,
                           compat="fixed" if (cov is not None or args.genie) else "reference")
