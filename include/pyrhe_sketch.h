@@ -186,6 +186,22 @@ int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, int nx, const
                           int64_t period, int n_sub, int n_batch, double* out, void* stream);
 
 /*
+ * One read of the stored block rows for all of their pass-2 products (the blk parts of the same Gram loops, base.py:568-628,
+ * when covariates are present: base.py:583-593).  x: 1..16 block-only rows (tot NULL; blk 16-byte aligned), evaluated as
+ * -blk * mul like in pyrhe_engine_loo_dots; y_sub: 1..16 tot-only rows of n_sub * period elements; y_flat: 0..16 tot-only
+ * rows of `period` elements (the covariate columns W_m).
+ *     out_sub [z][a][b]      = sum_{s, i} x_a[z][s * period + i] * y_sub_b[s * period + i]
+ *     out_flat[z][a][s][m]   = sum_i      x_a[z][s * period + i] * y_flat_m[i]                (NULL with ny_flat = 0)
+ *     out_self[z][a][b]      = sum_{s, i} blk_a * blk_b  (signs cancel)                       (NULL with want_self = 0)
+ * float64, device; deterministic; period a multiple of 32.  The same numbers as three pyrhe_engine_loo_dots calls (block rows
+ * x sub-strided rows, their nx * n_sub sub-rows x flat rows with n_sub = 1, block rows x themselves) for one pass over the
+ * store instead of three.  Asynchronous on `stream`; one stream per engine (shared scratch).
+ */
+int pyrhe_engine_loo_dots_multi(pyrhe_engine_t* e, const pyrhe_row_t* x, int nx, const pyrhe_row_t* y_sub, int ny_sub,
+                                const pyrhe_row_t* y_flat, int ny_flat, int want_self, int64_t period, int n_sub,
+                                int n_batch, double* out_sub, double* out_flat, double* out_self, void* stream);
+
+/*
  * Genotype coding of the packed buffers.  PLINK (default): the .bed body as it is.  VALUE: every 2-bit field holds the
  * allele-2 count itself (00->0, 10->1, 11->2) and 3 for a missing call: the kernels then skip the three-instruction
  * code -> count conversion they otherwise pay per dword in both contractions of both passes (-8 % GEMM 2 time).

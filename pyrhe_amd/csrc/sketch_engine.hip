@@ -960,6 +960,75 @@ extern "C" int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, in
     return PYRHE_OK;
 }
 
+extern "C" int pyrhe_engine_loo_dots_multi(pyrhe_engine_t* e, const pyrhe_row_t* x, int nx, const pyrhe_row_t* y_sub, int ny_sub,
+                                           const pyrhe_row_t* y_flat, int ny_flat, int want_self, int64_t period, int n_sub,
+                                           int n_batch, double* out_sub, double* out_flat, double* out_self, void* stream_) {
+    if (!e || !x || !y_sub || !out_sub) return fail(PYRHE_EINVAL, "NULL argument");
+    if (nx < 1 || nx > 16 || ny_sub < 1 || ny_sub > 16 || ny_flat < 0 || ny_flat > 16)
+        return fail(PYRHE_EINVAL, "loo_dots_multi takes 1..16 block rows, 1..16 sub-strided and 0..16 flat fixed rows");
+    if ((ny_flat > 0) != (y_flat != nullptr && out_flat != nullptr)) return fail(PYRHE_EINVAL, "flat rows and out_flat go together");
+    if ((want_self != 0) != (out_self != nullptr)) return fail(PYRHE_EINVAL, "want_self and out_self go together");
+    if (period <= 0 || period % 32) return fail(PYRHE_EINVAL, "period (%lld) must be a positive multiple of 32", (long long)period);
+    if (n_sub < 1 || n_sub > 65535 || n_batch < 1 || (int64_t)n_batch * 16 >= (1 << 30)) return fail(PYRHE_EINVAL, "n_sub / n_batch out of range");
+    for (int a = 0; a < nx; ++a)
+        if (x[a].tot || !x[a].blk || (((uintptr_t)x[a].blk | (uintptr_t)x[a].mul) & 15) || x[a].blk_batch_stride % 4)
+            return fail(PYRHE_EINVAL, "x row %d must be a 16-byte aligned block-only row", a);
+    for (int pass = 0; pass < 2; ++pass) {
+        const pyrhe_row_t* r = pass ? y_flat : y_sub;
+        for (int b = 0; b < (pass ? ny_flat : ny_sub); ++b)
+            if (!r[b].tot || r[b].blk || ((uintptr_t)r[b].tot & 15)) return fail(PYRHE_EINVAL, "fixed row %d must be a 16-byte aligned tot-only row", b);
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipSetDevice(e->device));
+    int nxp = 1;
+    while (nxp < nx) nxp *= 2;
+    const int64_t n_rows = (int64_t)n_batch * nxp;
+    const int rgs = (int)((n_rows + 63) / 64);
+    int64_t n_chunks = std::max<int64_t>(1, 4096 / ((int64_t)rgs * n_sub));
+    n_chunks = std::min<int64_t>(n_chunks, std::max<int64_t>(1, period / 256));
+    const int chunk = (int)(((period + n_chunks - 1) / n_chunks + 31) / 32 * 32);
+    n_chunks = (period + chunk - 1) / chunk;
+    const size_t one = (size_t)rgs * n_sub * n_chunks * 1024 * sizeof(double);
+    const int n_sets = 1 + (ny_flat > 0) + (want_self != 0);
+    if (e->dots_partial_bytes < one * n_sets) {
+        if (e->dots_partial) {
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipFree(e->dots_partial));
+        }
+        HIPCHK(hipMalloc(&e->dots_partial, one * n_sets));
+        e->dots_partial_bytes = one * n_sets;
+    }
+    double* ps = e->dots_partial;
+    double* pf = ny_flat > 0 ? ps + one / sizeof(double) : nullptr;
+    double* pg = want_self ? ps + (size_t)(1 + (ny_flat > 0)) * (one / sizeof(double)) : nullptr;
+    BlkRowTable tab;
+    for (int a = 0; a < kDescMax; ++a)
+        tab.r[a] = a < nx ? BlkRowDev{x[a].blk, x[a].mul, (long long)x[a].blk_batch_stride} : BlkRowDev{nullptr, nullptr, 0};
+    FixedRows Ys, Yf;
+    for (int c = 0; c < 16; ++c) {
+        Ys.p[c] = c < ny_sub ? y_sub[c].tot : nullptr;
+        Yf.p[c] = c < ny_flat ? y_flat[c].tot : nullptr;
+    }
+    dim3 grid((unsigned)((n_chunks + 3) / 4), n_sub, rgs);
+#define LM(F_, S_) blk_multi_dots_kernel<F_, S_><<<grid, 256, 0, stream>>>(tab, nx, nxp, n_batch, Ys, ny_sub, Yf, ny_flat, period, chunk, (int)n_chunks, ps, pf, pg)
+    if (ny_flat > 0) { if (want_self) LM(true, true); else LM(true, false); }
+    else { if (want_self) LM(false, true); else LM(false, false); }
+#undef LM
+    auto reduce = [&](const double* part, int kind, int ny, double* out) {
+        const int64_t n_out = (int64_t)n_batch * nx * (kind == 1 ? n_sub : 1) * ny;
+        const int n_part = (int)(kind == 1 ? n_chunks : n_chunks * n_sub);
+        int g_log2 = 0;
+        while (g_log2 < 6 && (n_part >> g_log2) > 8 && (n_out << g_log2) < (1 << 18)) ++g_log2;
+        blk_multi_reduce_kernel<<<(unsigned)(((n_out << g_log2) + 255) / 256), 256, 0, stream>>>(part, kind, (int)n_chunks, n_sub, nx, nxp, n_batch,
+                                                                                               ny, g_log2, out);
+    };
+    reduce(ps, 0, ny_sub, out_sub);
+    if (ny_flat > 0) reduce(pf, 1, ny_flat, out_flat);
+    if (want_self) reduce(pg, 2, nx, out_self);
+    HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
 extern "C" int pyrhe_recode_rows(uint8_t* packed, int64_t n_rows, int64_t pitch, int to_coding, void* stream_) {
     if (!packed) return fail(PYRHE_EINVAL, "NULL argument");
     if (pitch <= 0 || pitch % 4) return fail(PYRHE_EINVAL, "pitch must be a positive multiple of 4");

@@ -46,6 +46,7 @@ SYMBOLS = {
     "pyrhe_sum_blocks": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
     "pyrhe_sum_blocks_weighted": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     "pyrhe_engine_loo_dots": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
+    "pyrhe_engine_loo_dots_multi": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pyrhe_synth_genotypes": (_i32, [_vp, _i64, _i64, _i64, _u64, _i64, _vp]),
     "pyrhe_engine_info": (_i64, [_vp, _i32]),
     "pyrhe_engine_profile": (_i32, [_vp, _i32]),
@@ -372,6 +373,44 @@ class SketchEngine:
                                                   int(n_sub), int(n_batch), _ptr(out), _stream_ptr(self.device)),
                    "pyrhe_engine_loo_dots")
         return out
+
+    @staticmethod
+    def multi_ok(x: Sequence[Row], y_sub: Sequence[Row], y_flat: Sequence[Row], period: int) -> bool:
+        """Shapes ``loo_dots_multi`` takes: 1..16 aligned block-only rows, 1..16 / 0..16 tot-only fixed rows."""
+        def blk_ok(r):
+            return (r.tot is None and r.blk is not None and r.blk.data_ptr() % 16 == 0 and r.stride % 4 == 0
+                    and (r.mul is None or r.mul.data_ptr() % 16 == 0))
+        def tot_ok(r):
+            return r.tot is not None and r.blk is None and r.tot.data_ptr() % 16 == 0
+        return (1 <= len(x) <= 16 and 1 <= len(y_sub) <= 16 and len(y_flat) <= 16 and period % 32 == 0
+                and all(blk_ok(r) for r in x) and all(tot_ok(r) for r in y_sub) and all(tot_ok(r) for r in y_flat))
+
+    def loo_dots_multi(self, x: Sequence[Row], y_sub: Sequence[Row], y_flat: Sequence[Row], want_self: bool, period: int,
+                       n_sub: int, n_batch: int):
+        """One pass over the block rows ``x`` (evaluated as ``-blk * mul``) for ``out_sub [n_batch, nx, ny_sub]`` (summed over
+        the sub-rows), ``out_flat [n_batch, nx, n_sub, ny_flat]`` (one result per sub-row; None without flat rows) and
+        ``out_self [n_batch, nx, nx]`` (None unless ``want_self``): see ``pyrhe_engine_loo_dots_multi``."""
+        def pack(rows):
+            arr = (_RowStruct * max(len(rows), 1))()
+            for i, r in enumerate(rows):
+                arr[i].tot = None if r.tot is None else r.tot.data_ptr()
+                arr[i].blk = None if r.blk is None else r.blk.data_ptr()
+                arr[i].mul = None if r.mul is None else r.mul.data_ptr()
+                arr[i].blk_batch_stride = r.stride
+            return arr
+        f64 = dict(dtype=torch.float64, device=self.device)
+        out_sub = torch.empty((n_batch, len(x), len(y_sub)), **f64)
+        out_flat = torch.empty((n_batch, len(x), n_sub, len(y_flat)), **f64) if y_flat else None
+        out_self = torch.empty((n_batch, len(x), len(x)), **f64) if want_self else None
+        xa, sa, fa = pack(x), pack(y_sub), pack(y_flat)
+        with torch.cuda.device(self.device):
+            _check(self.lib.pyrhe_engine_loo_dots_multi(self._h, C.cast(xa, _vp), len(x), C.cast(sa, _vp), len(y_sub),
+                                                        C.cast(fa, _vp) if y_flat else None, len(y_flat), 1 if want_self else 0,
+                                                        int(period), int(n_sub), int(n_batch), _ptr(out_sub),
+                                                        None if out_flat is None else _ptr(out_flat),
+                                                        None if out_self is None else _ptr(out_self), _stream_ptr(self.device)),
+                   "pyrhe_engine_loo_dots_multi")
+        return out_sub, out_flat, out_self
 
     def profile(self, enable: bool):
         _check(self.lib.pyrhe_engine_profile(self._h, 1 if enable else 0), "pyrhe_engine_profile")

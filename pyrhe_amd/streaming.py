@@ -745,7 +745,8 @@ class SketchRunner:
         out = []
         for r in rows:
             for s_ in range(nc):
-                out.append(Row(None if r.tot is None else r.tot[s_], None if r.blk is None else r.blk[s_], r.mul, r.stride))
+                out.append(None if r is None else
+                           Row(None if r.tot is None else r.tot[s_], None if r.blk is None else r.blk[s_], r.mul, r.stride))
         return out
 
     def _lin_dots(self, x, y, n_sub, batch):
@@ -758,6 +759,44 @@ class SketchRunner:
         t = self._dots(tot_rows, y, n_sub, 1)
         b = self._dots(blk_rows, y, n_sub, batch)                  # rows evaluate to -blk
         return t + b, -b
+
+    def _blk_products(self, rows_blk, y_sub, y_flat, want_self, nc, batch):
+        """All pass-2 products of the block-only rows ``rows_blk`` (None = an exact zero row; rows evaluate to ``-blk``):
+        ``b_sub [batch, n, len(y_sub)]`` against the sub-strided fixed rows, ``b_flat [batch, n, nc, len(y_flat)]`` against
+        the flat fixed rows per sub-row (None without flat rows), ``b_self [batch, n, n]`` against themselves (None unless
+        asked).  ONE pass over the store through ``pyrhe_engine_loo_dots_multi`` where the shapes allow (<= 16 rows each),
+        otherwise the three ``loo_dots`` calls it stands for."""
+        n = len(rows_blk)
+        idx = [i for i, r in enumerate(rows_blk) if r is not None]
+        f64 = dict(dtype=torch.float64, device=self.device)
+        if not idx:
+            return (torch.zeros((batch, n, len(y_sub)), **f64),
+                    torch.zeros((batch, n, nc, len(y_flat)), **f64) if y_flat else None,
+                    torch.zeros((batch, n, n), **f64) if want_self else None)
+        live = [rows_blk[i] for i in idx]
+        multi = getattr(self.eng, "loo_dots_multi", None)
+        if multi is not None and self.eng.multi_ok(live, y_sub, y_flat, self.n_pad):
+            o_sub, o_flat, o_self = multi(live, y_sub, y_flat, want_self, self.n_pad, nc, batch)
+            if len(idx) == n:
+                return o_sub, o_flat, o_self
+            ix = torch.as_tensor(idx, device=self.device)
+            b_sub = torch.zeros((batch, n, len(y_sub)), **f64)
+            b_sub[:, ix] = o_sub
+            b_flat = b_self = None
+            if o_flat is not None:
+                b_flat = torch.zeros((batch, n, nc, len(y_flat)), **f64)
+                b_flat[:, ix] = o_flat
+            if o_self is not None:
+                b_self = torch.zeros((batch, n, n), **f64)
+                b_self[:, ix[:, None], ix[None, :]] = o_self
+            return b_sub, b_flat, b_self
+        b_sub = self._dots(rows_blk, y_sub, nc, batch)
+        b_flat = None
+        if y_flat:
+            b_flat = self._dots(self._sub_rows([r if r is not None else None for r in rows_blk], nc), y_flat, 1, batch)
+            b_flat = b_flat.reshape(batch, n, nc, len(y_flat))
+        b_self = self._dots(rows_blk, rows_blk, nc, batch) if want_self else None
+        return b_sub, b_flat, b_self
 
     def _to_host(self, t: torch.Tensor) -> np.ndarray:
         """Device tensor -> NumPy through a cached pinned buffer (asynchronous copy, then an event poll)."""
@@ -846,9 +885,10 @@ class SketchRunner:
                 fixed.append(Row(self.Z64[s0:s0 + nc]))
             if use_cov:
                 fixed.append(Row(self.UZ64[s0:s0 + nc]))
-            bpart = self._dots(A_blk, fixed, nc, batch)           # block rows evaluate to -blk: -<b_a, fixed>
+            # one pass over the stored XXz rows: -<b_a, fixed>, the projections -<b_a[s], W_m> and <b_a, b_b>
+            bpart, bA_flat, bA_self = self._blk_products(A_blk, fixed, Wr if use_cov else [], True, nc, batch)
             g = self._dots(A_tot, fixed, nc, 1) + bpart
-            gram = acc(gram, g[:, :, :ne] + bpart[:, :, :ne].transpose(1, 2) + self._dots(A_blk, A_blk, nc, batch))
+            gram = acc(gram, g[:, :, :ne] + bpart[:, :, :ne].transpose(1, 2) + bA_self)
             col = ne
             if self.genie_model is not None:
                 tz = acc(tz, g[:, :, col]); col += 1
@@ -856,13 +896,18 @@ class SketchRunner:
                 tk = acc(tk, g[:, :, col])
                 Cr = self._loo_rows(tot_C, store, "UZ", "eUZ", nC, s0, nc)
                 Dr = [Row(D_tot[a, s0:s0 + nc]) for a in range(D_tot.shape[0])] + ([Row(nD[s0:s0 + nc])] if nD is not None else [])
-                gCD = acc(gCD, self._lin_dots(Cr, Dr, nc, batch)[0])      # <XXUz_a (LOO), UXXz_b (whole data)>
+                C_tot = [Row(r.tot) for r in Cr]
+                C_blk = [None if r.blk is None else Row(None, r.blk, r.mul, r.stride) for r in Cr]
+                # one pass over the stored XXUz rows: -<c_a, UXXz_b> and the projections -<c_a[s], W_m>
+                bC_sub, bC_flat, _ = self._blk_products(C_blk, Dr, Wr, False, nc, batch)
+                gCD = acc(gCD, self._dots(C_tot, Dr, nc, 1) + bC_sub)     # <XXUz_a (LOO), UXXz_b (whole data)>
                 # projections onto the covariates, P[z, a, s, m] = <row_a[s], W_m>; U = W Q W^T is applied through them:
                 # <U A_a, A_b> = sum_s PA[a,s] Q PA[b,s],  <C_a, U blkA_b> = sum_s PC[a,s] Q PblkA[b,s]  (base.py:583-593;
                 # UXXz_b = whole-data UXXz_b - U(block XXz_b), streaming_rhe.py:35-36)
-                pa, pba = (t.reshape(batch, ne, nc, c) for t in self._lin_dots(self._sub_rows(A, nc), Wr, 1, batch))
-                PA_l.append(pa); PbA_l.append(pba)
-                PC_l.append(self._lin_dots(self._sub_rows(Cr, nc), Wr, 1, batch)[0].reshape(batch, ne, nc, c))
+                tA = self._dots(self._sub_rows(A_tot, nc), Wr, 1, 1).reshape(1, ne, nc, c)      # whole-data parts: once per pass
+                tC = self._dots(self._sub_rows(C_tot, nc), Wr, 1, 1).reshape(1, ne, nc, c)
+                PA_l.append(tA + bA_flat); PbA_l.append(-bA_flat)
+                PC_l.append(tC + bC_flat)
         if use_cov:
             PA, PbA, PC = (torch.cat(l, dim=2) if len(l) > 1 else l[0] for l in (PA_l, PbA_l, PC_l))
             Q = self.Q64

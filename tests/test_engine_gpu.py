@@ -410,3 +410,41 @@ def test_lists_longer_than_a_segment(dev, precision):
         assert (sk[b] - s1[0]).abs().max().item() <= 2e-6 * scale, b
         assert torch.allclose(nm[b], n1[0], rtol=2e-6, atol=0), b
     eng.close()
+
+
+@pytest.mark.parametrize("nx,nys,nyf,n_sub,batch,want_self", [(8, 9, 10, 3, 7, True), (3, 5, 0, 2, 9, True), (5, 16, 16, 1, 33, False),
+                                                              (16, 1, 4, 2, 4, True), (1, 1, 1, 4, 40, True), (7, 2, 3, 5, 3, False)])
+def test_loo_dots_multi_equals_separate_calls(dev, nx, nys, nyf, n_sub, batch, want_self):
+    """pyrhe_engine_loo_dots_multi (one pass over the block rows for the products with the sub-strided fixed rows, with the
+    flat fixed rows per sub-row, and with themselves) against the three pyrhe_engine_loo_dots calls it replaces."""
+    from pyrhe_amd import engine
+    from pyrhe_amd.engine import Row
+    period = 1024
+    L = period * n_sub
+    g = torch.Generator().manual_seed(nx * 1000 + nys * 10 + nyf)
+    eng = engine.SketchEngine(4 * 256, 4 * 256, max_entries=32, device=dev)
+    store = torch.randn((batch, nx, L), generator=g, dtype=torch.float32).to(dev)
+    mul = torch.randn(period, generator=g, dtype=torch.float32).to(dev)
+    ys = torch.randn((nys, L), generator=g, dtype=torch.float64).to(dev)
+    yf = torch.randn((max(nyf, 1), period), generator=g, dtype=torch.float64).to(dev)
+    x = [Row(None, store[0, a], mul if a % 2 else None, store.stride(0)) for a in range(nx)]
+    y_sub = [Row(ys[b]) for b in range(nys)]
+    y_flat = [Row(yf[m]) for m in range(nyf)]
+    assert eng.multi_ok(x, y_sub, y_flat, period)
+    o_sub, o_flat, o_self = eng.loo_dots_multi(x, y_sub, y_flat, want_self, period, n_sub, batch)
+    r_sub = eng.loo_dots(x, y_sub, period, n_sub, batch)
+    tol = lambda ref: 1e-12 * ref.abs().max().item() + 1e-300
+    assert (o_sub - r_sub).abs().max().item() <= tol(r_sub)
+    if nyf:
+        xs = [Row(None, store[0, a, s_ * period:(s_ + 1) * period], mul if a % 2 else None, store.stride(0))
+              for a in range(nx) for s_ in range(n_sub)]
+        r_flat = eng.loo_dots(xs, y_flat, period, 1, batch).reshape(batch, nx, n_sub, nyf)
+        assert (o_flat - r_flat).abs().max().item() <= tol(r_flat)
+    else:
+        assert o_flat is None
+    if want_self:
+        r_self = eng.loo_dots(x, x, period, n_sub, batch)
+        assert (o_self - r_self).abs().max().item() <= tol(r_self)
+    else:
+        assert o_self is None
+    eng.close()
