@@ -55,6 +55,10 @@ def parse_args():
     ap.add_argument("--verify", action="store_true", help="also run pass 2 + solve and print sigma^2")
     ap.add_argument("--h2", type=float, default=0.5, help="heritable share of the --verify phenotype")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra timed passes in the single-rounding f16 mode")
+    ap.add_argument("--missing-rate", type=float, default=0.0,
+                    help="cross-check aid (tools/verify_sweep.sh): plant missing calls at this rate -- the imputation path "
+                         "(block statistics, replayed NumPy draws, fill values in both contractions) then runs in every pass")
+    ap.add_argument("--drop-indv", type=int, default=0, help="cross-check aid: individuals without a phenotype (keep mask)")
     return ap.parse_args()
 
 
@@ -114,27 +118,38 @@ def main():
     r1 = plan.range(j1 - 1)[1] if j1 > j0 else 0
     t_gen = time.perf_counter()
     geno = eng_mod.synth_genotypes(r1 - r0, N, SYNTH_SEED, r0, dev)          # resident in HBM before timing
+    if args.missing_rate > 0:                    # PLINK missing code 01 in the first call of random bytes, before the recode
+        gen = torch.Generator(device=dev).manual_seed(99)
+        for a in range(0, geno.shape[0], 4096):
+            part = geno[a:a + 4096]
+            hit = torch.rand(part.shape, device=dev, generator=gen) < args.missing_rate * 4
+            part[hit] = (part[hit] & 0xFC) | 0x01
+        del part, hit
     coding = os.environ.get("PYRHE_CODING", "value")
     if coding == "value":
         eng_mod.recode_rows(geno, "value")       # the load-time recode of the product path (models.py), outside the timing
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
-    engine = eng_mod.SketchEngine(N, N, max_entries=engine_capacity(plan), precision=args.precision, device=dev,
+    dropped = sorted(np.random.default_rng(5).choice(N, args.drop_indv, replace=False).tolist()) if args.drop_indv else []
+    keep_idx = np.setdiff1d(np.arange(N), np.asarray(dropped, dtype=np.int64))
+    Nk = len(keep_idx)                           # individuals with a phenotype: every per-individual input has this length
+    check_missing = args.missing_rate > 0
+    engine = eng_mod.SketchEngine(N, Nk, max_entries=engine_capacity(plan), precision=args.precision, device=dev,
                                   sub_snps=args.sub_snps or engine_capacity(plan))
     engine.set_coding(coding)
     np.random.seed(0)
-    Z = np.random.randn(N, k)                                               # NumPy legacy stream, seed 0
-    y = np.random.default_rng(1).normal(size=N); y -= y.mean()
+    Z = np.random.randn(Nk, k)                                              # NumPy legacy stream, seed 0
+    y = np.random.default_rng(1).normal(size=Nk); y -= y.mean()
     if args.verify and args.h2 > 0:
         # heritable phenotype for the parity check between precision modes: y = a * (K r) + b * noise, K r = X X^T r / M
-        r = np.random.default_rng(7).normal(size=(N, 1))
+        r = np.random.default_rng(7).normal(size=(Nk, 1))
         # always built in the parity-safe mode, so that every --precision is verified on the SAME phenotype
-        eng_y = eng_mod.SketchEngine(N, N, max_entries=engine_capacity(plan), precision="i8x3", device=dev, sub_snps=args.sub_snps or engine_capacity(plan))
+        eng_y = eng_mod.SketchEngine(N, Nk, max_entries=engine_capacity(plan), precision="i8x3", device=dev, sub_snps=args.sub_snps or engine_capacity(plan))
         eng_y.set_coding(coding)
-        rr = SketchRunner(eng_y, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=r, seed=0, streaming=True)
-        rr.begin_trait(y, check_missing=False)
+        rr = SketchRunner(eng_y, geno, plan, (j0, j1), n_orig=N, missing_indv=dropped, Z=r, seed=0, streaming=True)
+        rr.begin_trait(y, check_missing=check_missing)
         rr.pass1()
-        g = rr.tot_sk[0, 0, :N].cpu().numpy()
+        g = rr.tot_sk[0, 0, :N].cpu().numpy()[keep_idx]
         del rr
         eng_y.close()
         g = (g - g.mean()) / g.std()
@@ -142,21 +157,21 @@ def main():
         y -= y.mean()
     cov = None
     if args.n_cov > 0:
-        cov = np.concatenate([np.ones((N, 1)), np.random.default_rng(2).normal(size=(N, args.n_cov - 1))], axis=1)
+        cov = np.concatenate([np.ones((Nk, 1)), np.random.default_rng(2).normal(size=(Nk, args.n_cov - 1))], axis=1)
     env = None
     if args.genie:
-        env = np.random.default_rng(3).integers(0, 2, size=N).astype(np.float64)     # Bernoulli(0.5)
+        env = np.random.default_rng(3).integers(0, 2, size=Nk).astype(np.float64)     # Bernoulli(0.5)
     # one engine per pass over the genotypes: the column groups (Z, UZ, e.Z, e.UZ of k columns each) that do not fit one
     # engine's 30 right-hand columns go to further engines (k = 10: one, or two for GxE + covariates)
     engines = [engine]
     for _ in range(n_engines_needed(k, cov is not None, bool(args.genie)) - 1):
-        engines.append(eng_mod.SketchEngine(N, N, max_entries=engine_capacity(plan), precision=args.precision, device=dev,
+        engines.append(eng_mod.SketchEngine(N, Nk, max_entries=engine_capacity(plan), precision=args.precision, device=dev,
                                             sub_snps=args.sub_snps or engine_capacity(plan)))
         engines[-1].set_coding(coding)
-    runner = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, cov=cov, env=env,
+    runner = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, env=env,
                           genie_model=args.genie, seed=0, streaming=True,
                           compat="fixed" if (cov is not None or args.genie) else "reference")
-    runner.begin_trait(y, check_missing=False)      # the generator emits no missing calls (contract of synth_kernel)
+    runner.begin_trait(y, check_missing=check_missing)      # the generator itself emits no missing calls (contract of synth_kernel)
 
     def barrier():
         if world > 1:
@@ -273,11 +288,11 @@ def main():
         # headline, never as `value` -- its sigma^2 error is ~2^-12/sqrt(N k), not bounded by 1e-5 at every size
         del runner
         engine.close()
-        engine = eng_mod.SketchEngine(N, N, max_entries=engine_capacity(plan), precision="f16", device=dev, sub_snps=args.sub_snps or engine_capacity(plan))
+        engine = eng_mod.SketchEngine(N, Nk, max_entries=engine_capacity(plan), precision="f16", device=dev, sub_snps=args.sub_snps or engine_capacity(plan))
         engine.set_coding(coding)
-        runner = SketchRunner(engine, geno, plan, (j0, j1), n_orig=N, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True,
+        runner = SketchRunner(engine, geno, plan, (j0, j1), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, seed=0, streaming=True,
                               compat="fixed" if cov is not None else "reference")
-        runner.begin_trait(y, check_missing=False)
+        runner.begin_trait(y, check_missing=check_missing)
         runner.pass1()
         barrier()
         t0 = time.perf_counter()

@@ -16,3 +16,6 @@ run "odd-N" --n-indv 33331 --n-snp 70001 --jn 7 --n-bin 5
 run "k25+cov(2 engines)" --n-indv 60000 --n-snp 40000 --jn 10 --k 25 --n-cov 3
 run "genie+cov(2 engines)" --n-indv 60000 --n-snp 40000 --jn 10 --genie G+GxE --n-cov 5 --n-bin 2
 run "k40" --n-indv 30000 --n-snp 30000 --jn 6 --k 40
+run "missing+dropped" --n-indv 80000 --n-snp 80000 --jn 10 --missing-rate 0.01 --drop-indv 777
+run "missing+8bins+cov" --n-indv 60000 --n-snp 60000 --jn 10 --n-bin 8 --n-cov 6 --missing-rate 0.02 --drop-indv 5
+run "missing+genie" --n-indv 50000 --n-snp 50000 --jn 5 --genie G+GxE --missing-rate 0.005
