@@ -51,6 +51,30 @@ __global__ void cols_kernel(const uint8_t* p, int64_t pitch, int n_rows, uint32_
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// GEMM 2 pattern as the packed int8 kernel runs it: 16 rows per step (lane (n, q) reads W bytes of rows 16q+j), a
+// workgroup barrier every 2 steps (BAR) so that sibling waves stay on the same 128-byte lines; PAIR: waves w, w^1 read the
+// SAME 16*W bytes (each would use half of them) -- useful bytes are counted once.
+template <int W, bool BAR, bool PAIR>
+__global__ void cols16_kernel(const uint8_t* p, int64_t pitch, int n_rows, uint32_t* sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+    const int wv = blockIdx.x * (blockDim.x >> 6) + wave;
+    const int64_t grp = PAIR ? wv >> 1 : wv;
+    const bool live = grp * 16 * W < pitch;
+    const uint8_t* cp = p + (live ? grp : 0) * 16 * W + n * W;
+    uint32_t acc = 0;
+    for (int kb = 0; kb < n_rows / 64; ++kb) {
+        if (BAR && (kb & 1) == 0) __syncthreads();
+        if (!live) continue;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint8_t* a = cp + (int64_t)(kb * 64 + q * 16 + j) * pitch;
+            if (W == 4) acc += *(const uint32_t*)a;
+            else { uint2 g = *(const uint2*)a; acc += g.x ^ g.y; }
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 __global__ void linear_kernel(const uint4* p, int64_t n16, uint32_t* sink) {
     uint32_t acc = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) { uint4 g = p[i]; acc += g.x ^ g.y ^ g.z ^ g.w; }
@@ -107,6 +131,16 @@ int main() {
         run(cols_kernel<8>, 8, 4, "cols: W=8 (128 B/row/wave), 4 waves = 512 B/row/WG (today f16)");
         run(cols_kernel<8>, 8, 8, "cols: W=8, 8 waves = 1 KB/row/WG");
         run(cols_kernel<8>, 8, 16, "cols: W=8, 16 waves = 2 KB/row/WG");
+        auto run16 = [&](auto kern, int w, int waves, bool pair, const char* name) {
+            const int64_t groups = pitch / (16 * w);
+            const int grid = (int)((groups * (pair ? 2 : 1) + waves - 1) / waves);
+            timeit(name, [&]() { kern<<<grid, 64 * waves>>>(arena, pitch, n_rows, sink); });
+        };
+        run16(cols16_kernel<4, false, false>, 4, 4, false, "cols16: W=4, 16 rows/step, no barrier");
+        run16(cols16_kernel<4, true, false>, 4, 4, false, "cols16: W=4, 16 rows/step, barrier every 2 steps (packed int8 kernel)");
+        run16(cols16_kernel<8, true, false>, 8, 4, false, "cols16: W=8, barrier every 2 steps, distinct data per wave");
+        run16(cols16_kernel<8, true, true>, 8, 4, true, "cols16: W=8, wave PAIRS read the same 128 B, barrier (useful bytes once)");
+        run16(cols16_kernel<8, false, true>, 8, 4, true, "cols16: W=8, wave PAIRS read the same 128 B, no barrier");
         run(cols_kernel<16>, 16, 4, "cols: W=16 (256 B/row/wave), 4 waves = 1 KB/row/WG");
         run(cols_kernel<16>, 16, 8, "cols: W=16, 8 waves = 2 KB/row/WG");
     }
