@@ -15,7 +15,7 @@ def grab(section, kern, counter):
     return int(m.group(1)), float(m.group(2))
 
 
-names = {"gemm1_i8_kernel": "void gemm1_i8_kernel<1, false, 0, true>", "gemm2_i8p_kernel": "void gemm2_i8p_kernel<false, true>",
+names = {"gemm1_i8_kernel": "void gemm1_i8_kernel<3, false, 0, true>", "gemm2_i8p_kernel": "void gemm2_i8p_kernel<1, false, true>",
          "gemm2_kernel_f16x2": "_Z12gemm2_kernelILi1ELi2ELi1ELb1ELb0ELi0",
          "gemm1_kernel_f16": "_Z12gemm1_kernelILi1ELi1ELb0ELb0ELi0ELb1", "gemm2_kernel_f16": "_Z12gemm2_kernelILi1ELi1ELi2ELb0ELb0ELi0"}
 out = {"_comment": __doc__.strip(), "n_indv": N, "block_snps": 10000, "kernels": {}}
