@@ -59,6 +59,7 @@ def parse_args():
                     help="cross-check aid (tools/verify_sweep.sh): plant missing calls at this rate -- the imputation path "
                          "(block statistics, replayed NumPy draws, fill values in both contractions) then runs in every pass")
     ap.add_argument("--drop-indv", type=int, default=0, help="cross-check aid: individuals without a phenotype (keep mask)")
+    ap.add_argument("--dom", action="store_true", help="RHE_DOM: additive + dominance sketches (pyrhe_engine_sketch_block_dom)")
     return ap.parse_args()
 
 
@@ -169,7 +170,7 @@ def main():
                                             sub_snps=args.sub_snps or engine_capacity(plan)))
         engines[-1].set_coding(coding)
     runner = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, env=env,
-                          genie_model=args.genie, seed=0, streaming=True,
+                          genie_model=args.genie, seed=0, streaming=True, dom=args.dom,
                           compat="fixed" if (cov is not None or args.genie) else "reference")
     runner.begin_trait(y, check_missing=check_missing)      # the generator itself emits no missing calls (contract of synth_kernel)
 
@@ -283,7 +284,7 @@ def main():
             out["config"]["sigma_total"] = [float(v) for v in sig[-1]]
             out["config"]["sigma_se"] = [float(v) for v in est.jackknife_se(sig[:-1], jn)]
 
-    if not args.no_alt and args.precision in ("f16x2", "i8x3"):
+    if not args.no_alt and not args.dom and args.precision in ("f16x2", "i8x3"):
         # the same pass in the single-rounding mode (1 MFMA per fragment, subnormal unpack): reported beside the
         # headline, never as `value` -- its sigma^2 error is ~2^-12/sqrt(N k), not bounded by 1e-5 at every size
         del runner

@@ -19,3 +19,6 @@ run "k40" --n-indv 30000 --n-snp 30000 --jn 6 --k 40
 run "missing+dropped" --n-indv 80000 --n-snp 80000 --jn 10 --missing-rate 0.01 --drop-indv 777
 run "missing+8bins+cov" --n-indv 60000 --n-snp 60000 --jn 10 --n-bin 8 --n-cov 6 --missing-rate 0.02 --drop-indv 5
 run "missing+genie" --n-indv 50000 --n-snp 50000 --jn 5 --genie G+GxE --missing-rate 0.005
+run "dom" --n-indv 60000 --n-snp 60000 --jn 10 --dom
+run "dom+3bins+cov+missing" --n-indv 40000 --n-snp 50000 --jn 5 --dom --n-bin 3 --n-cov 4 --missing-rate 0.01
+run "dom-long-blocks" --n-indv 20000 --n-snp 150000 --jn 2 --dom
