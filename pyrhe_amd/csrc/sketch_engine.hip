@@ -429,6 +429,10 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     static const bool g2p_off = getenv("PYRHE_G2_PACKED") && atoi(getenv("PYRHE_G2_PACKED")) == 0;
     const bool g2p_ok = !g2p_off && e->i8 && e->parts == 2 && e->n_sketch >= 1 && e->n_sketch <= 2 * kI8pCols && !dom && !g2i8;
     const int g2p_ng = e->n_sketch <= kI8pCols ? 1 : 2;        // column groups of 10 = pairs of A tiles
+    // RHE_DOM (per-list flow, three GEMM 2 launches per list, the third under the [g == 2] view): the packed kernel as a
+    // one-segment launch, for cohorts whose sample range alone fills the chip; lists go in pieces of <= 16384 entries
+    const bool g2p_dom = !g2p_off && e->i8 && e->parts == 2 && dom && !g2i8 && e->n_sketch >= 1 && e->n_sketch <= kI8pCols &&
+                         e->n_pad >= 192 * 1024;
 
     if (dom && !e->dom_ws) {
         const size_t S = (size_t)e->sub_snps, nc = 16 * kMaxTiles;
@@ -511,7 +515,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             ProfScope ps(e, stream, 1);
             const int64_t threads = (int64_t)n_kb * e->parts * e->nto * 64;
             const unsigned grid = (unsigned)std::max<int64_t>((threads + 255) / 256, (int64_t)tab.nseg * e->n_norm);
-            if (g2p_ok && segmode && gv == 0) {
+            if ((g2p_ok && segmode && gv == 0) || (g2p_dom && segmode)) {
                 const unsigned gridp = (unsigned)std::max<int64_t>(((int64_t)n_kb * 64 * g2p_ng + 255) / 256, (int64_t)tab.nseg * e->n_norm);
                 mid2_i8p_kernel<<<gridp, 256, 0, stream>>>(Wsrc, coef, e->n_sketch, 2 * g2p_ng, wmaxp, (int4v*)e->wfrag, e->corr, e->wscale, rows, e->rows32,
                                                            nsrc, ndst, e->n_norm, tab);
@@ -568,7 +572,16 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         }
         ProfScope ps(e, sB2, 2);
 #define G2(NTO_, PARTS_, IW_, EX_, GV_) launch_gemm2<NTO_, PARTS_, IW_, EX_, GV_>(e, packed, n_kb, kbps, splits, fill, outp, mode, partial, sB2, gtab)
-        if (g2p_ok && segmode && gv == 0) {
+        if (g2p_dom && segmode) {
+            dim3 grid((unsigned)((e->n_pad + 1023) / 1024), tab.nseg);
+            const size_t lds = (size_t)kbps * 128;
+#define L2D(MISS_, VC_, GV_) gemm2_i8p_kernel<1, MISS_, VC_, GV_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, tab)
+#define L2E(GV_) do { if (e->vc) { if (fill) L2D(true, true, GV_); else L2D(false, true, GV_); } \
+                      else { if (fill) L2D(true, false, GV_); else L2D(false, false, GV_); } } while (0)
+            if (gv == 0) L2E(0); else L2E(1);
+#undef L2E
+#undef L2D
+        } else if (g2p_ok && segmode && gv == 0) {
             dim3 grid((unsigned)((e->n_pad + 1023) / 1024 * g2p_ng), tab.nseg);       // NG = 2: a workgroup covers 512 samples
             const size_t lds = (size_t)kbps * 128;
 #define L2P(NG_, MISS_, VC_) gemm2_i8p_kernel<NG_, MISS_, VC_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, tab)
@@ -682,11 +695,12 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             continue;
         }
         bool first = true;
-        for (int64_t s0 = 0; s0 < n_b; s0 += e->sub_snps) {
-            const int n = (int)std::min<int64_t>(e->sub_snps, n_b - s0);
+        const int64_t list_step = g2p_dom ? std::min<int64_t>(e->sub_snps, 512 * 32) : e->sub_snps;   // packed GEMM 2: row list in LDS
+        for (int64_t s0 = 0; s0 < n_b; s0 += list_step) {
+            const int n = (int)std::min<int64_t>(list_step, n_b - s0);
             const int32_t* rows = entries + offsets_host[b] + s0;
             const int n32 = (n + kstep - 1) / kstep * kstep;
-            const int n_kb = n32 / kstep;
+            const int n_kb = g2p_dom ? 2 * ((n + 63) / 64) : n32 / kstep;      // packed GEMM 2: 64-entry K blocks, counted in 32s
             const int set = (int)(e->sub_counter & 1);
             e->use_set(set);
             if (piped && e->sub_counter >= 2) HIPCHK(hipStreamWaitEvent(e->sA, e->evB[set], 0));   // GEMM 2 of sub-block g-2 is done with this set
@@ -712,7 +726,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             }
             if (e->n_sketch) {
                 const int rc = run_gemm2(0, e->Wtmp, e->mu, e->wmax, n, n_kb, outb, acc_now, set, rows, e->n_norm ? e->vsq : nullptr,
-                                         e->n_norm ? normb : nullptr, tab, false);
+                                         e->n_norm ? normb : nullptr, tab, g2p_dom);
                 if (rc) return rc;
             }
             if (dom) {
@@ -730,11 +744,11 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 }
                 if (e->n_sketch) {
                     int rc = run_gemm2(0, e->Wtmp, e->cmu, e->wmax, n, n_kb, outd, acc_now, set, rows, e->n_norm ? e->vsq2 : nullptr,
-                                       e->n_norm ? normd : nullptr, tab, false);
+                                       e->n_norm ? normd : nullptr, tab, g2p_dom);
                     if (rc) return rc;
                     HIPCHK(hipMemsetAsync(e->corr, 0, 16 * kMaxTiles * sizeof(double), stream));
                     tab.acc[0] = 1;
-                    rc = run_gemm2(1, e->Wtmp2, e->zcoef, e->wmax2, n, n_kb, outd, true, set, rows, nullptr, nullptr, tab, false);
+                    rc = run_gemm2(1, e->Wtmp2, e->zcoef, e->wmax2, n, n_kb, outd, true, set, rows, nullptr, nullptr, tab, g2p_dom);
                     if (rc) return rc;
                 }
             }

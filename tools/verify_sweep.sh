@@ -22,3 +22,4 @@ run "missing+genie" --n-indv 50000 --n-snp 50000 --jn 5 --genie G+GxE --missing-
 run "dom" --n-indv 60000 --n-snp 60000 --jn 10 --dom
 run "dom+3bins+cov+missing" --n-indv 40000 --n-snp 50000 --jn 5 --dom --n-bin 3 --n-cov 4 --missing-rate 0.01
 run "dom-long-blocks" --n-indv 20000 --n-snp 150000 --jn 2 --dom
+run "dom-N200k-packed" --n-indv 200000 --n-snp 40000 --jn 4 --dom --missing-rate 0.01 --drop-indv 100
