@@ -94,7 +94,7 @@ struct pyrhe_engine {
     float* keep = nullptr;        // [n_pad] private copy
     // per sub-block workspace (one zeroed region first: P | wmax | corr)
     uint8_t* ws = nullptr;
-    size_t ws_bytes = 0, zero_bytes = 0;
+    size_t ws_bytes = 0, zero_bytes = 0, zero_tail = 0;   // zero_tail: offset of the small per-segment slots behind P
     float* P = nullptr;
     uint32_t* wmax = nullptr;
     double* corr = nullptr;
@@ -202,6 +202,7 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     const size_t oP = carve(S * ncolmax * sizeof(float) * (e->i8 ? 3 : 1));
     static_assert(kSegCols == 16 * kMaxTiles, "segment slots hold one value per logical column");
     const size_t oWmax = carve((size_t)kMaxSeg * kSegCols * sizeof(uint32_t));
+    e->zero_tail = oWmax;
     const size_t oCorr = carve((size_t)kMaxSeg * kSegCols * sizeof(double));
     e->zero_bytes = off;
     const size_t oVsq = carve(S * PYRHE_MAX_COLS * sizeof(double));
@@ -455,6 +456,15 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         e->zcoef = (float*)(e->dom_ws + oZc);
     }
 
+    // zero P for the n entries of this launch (not the whole sub_snps-sized buffer: 25 MB per call at 65536 entries) and the
+    // per-segment maxima / corrections behind it
+    auto zero_ws = [&](int n) -> int {
+        const size_t pbytes = std::min(e->zero_tail, (size_t)n * ncol_p * sizeof(float));
+        HIPCHK(hipMemsetAsync(e->ws, 0, pbytes, stream));
+        HIPCHK(hipMemsetAsync(e->ws + e->zero_tail, 0, e->zero_bytes - e->zero_tail, stream));
+        return PYRHE_OK;
+    };
+
     // ---- GEMM 1 of one entry list, genotype view gv, into Pbuf (zeroed by the caller)
     auto run_gemm1 = [&](int gv, const int32_t* rows, int n, float* Pbuf) {
         const int gx = (n + 255) / 256;
@@ -656,7 +666,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             e->use_set(set);
             if (piped && e->sub_counter >= 2) HIPCHK(hipStreamWaitEvent(e->sA, e->evB[set], 0));
             e->sub_counter++;
-            HIPCHK(hipMemsetAsync(e->ws, 0, e->zero_bytes, stream));
+            { const int rcz = zero_ws(n); if (rcz) return rcz; }
             run_gemm1(0, rows, n, e->P);
             {
                 ProfScope ps(e, stream, 1);
@@ -711,7 +721,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             tab.start[1] = n;
             tab.kb0[1] = n_kb;
             tab.acc[0] = acc_now ? 1 : 0;
-            HIPCHK(hipMemsetAsync(e->ws, 0, e->zero_bytes, stream));
+            { const int rcz = zero_ws(n); if (rcz) return rcz; }
             run_gemm1(0, rows, n, e->P);
             {
                 ProfScope ps(e, stream, 1);
