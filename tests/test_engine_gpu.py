@@ -448,3 +448,46 @@ def test_loo_dots_multi_equals_separate_calls(dev, nx, nys, nyf, n_sub, batch, w
     else:
         assert o_self is None
     eng.close()
+
+
+@pytest.mark.parametrize("coding,with_fill", [("value", False), ("plink", True), ("value", True)])
+def test_large_cohort_paths_int8_vs_fp16(dev, coding, with_fill):
+    """At >= 196608 samples the int8 engine takes paths the small fixtures never reach: a single list through the
+    segmented flow (packed int8 GEMM 2) and RHE_DOM's three GEMM 2 launches on the packed kernel under both genotype
+    views, lists cut into 16384-entry pieces.  Same inputs through the fp16 hi+lo engine (other kernels in every stage):
+    additive and dominance sketches and norms agree to 1e-5 of the largest entry."""
+    from pyrhe_amd import engine
+    n, m, k = 200_000, 18_000, 10
+    rng = np.random.default_rng(21)
+    packed = engine.synth_genotypes(m, n, 9, 0, dev)
+    fill = None
+    if with_fill:
+        rows = torch.as_tensor(rng.choice(m, 400, replace=False), device=dev)
+        packed[rows, 7] = (packed[rows, 7] & 0xF3) | 0x04          # missing call (01) in the second crumb of byte 7
+        fill = torch.zeros(m, dtype=torch.float32, device=dev)
+        fill[rows] = torch.as_tensor(rng.integers(0, 3, 400), dtype=torch.float32, device=dev)
+    if coding == "value":
+        packed = engine.recode_rows(packed, "value")
+    lst = np.sort(rng.choice(m, 17_000, replace=False)).astype(np.int32)       # > 16384: two pieces, the second accumulates
+    entries = torch.from_numpy(lst).to(dev)
+    outs = {}
+    for precision in ("i8x3", "f16x2"):
+        eng = engine.SketchEngine(n, n, max_entries=m, precision=precision, device=dev)
+        eng.set_coding(coding)
+        keep = eng.keep_vector([])
+        g = torch.Generator().manual_seed(4)
+        Z = torch.zeros((k, eng.n_pad), device=dev)
+        Z[:, :n] = torch.randn((k, n), generator=g).to(dev)
+        y = torch.zeros((1, eng.n_pad), device=dev)
+        y[:, :n] = torch.randn((1, n), generator=g).to(dev)
+        eng.set_rhs(Z, y, keep)
+        sk, nm, _ = eng.sketch_block(packed, entries, [0, len(lst)], fill=fill)
+        a, na, d, nd = eng.sketch_block_dom(packed, entries, [0, len(lst)], fill=fill)
+        torch.cuda.synchronize()
+        outs[precision] = [t.clone() for t in (sk, nm, a, na, d, nd)]
+        eng.close()
+    # 17 000 SNPs per sum: the fp16 engine accumulates them in float32 (a few 1e-6 of the largest entry), the int8 engine in
+    # exact int32 -- the bound here is the parity bound, not the 2e-6 of the short lists above
+    for x, r in zip(outs["i8x3"], outs["f16x2"]):
+        assert (x - r).abs().max().item() <= 1e-5 * r.abs().max().item()
+    assert torch.equal(outs["i8x3"][0], outs["i8x3"][2])          # the additive sketch of the dominance call is the same kernel path
