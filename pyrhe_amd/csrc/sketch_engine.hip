@@ -177,6 +177,12 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     e->parts = (precision == PYRHE_PREC_F16X2 || precision == PYRHE_PREC_I8X3) ? 2 : 1;
     e->exact = precision != PYRHE_PREC_F16 && precision != PYRHE_PREC_I8X3_F16;
     e->i8 = precision == PYRHE_PREC_I8X3 || precision == PYRHE_PREC_I8X3_F16;
+    // int8 GEMM 1 accumulates |digit| <= 128 times a genotype <= 3 (an unfilled missing code) over the samples in int32
+    if (e->i8 && (int64_t)e->n_pad * 3 * 128 >= (int64_t)1 << 31) {
+        const long long np = (long long)e->n_pad;
+        delete e;
+        return fail(PYRHE_EINVAL, "%lld samples overflow the int32 accumulators of the int8 modes; use PYRHE_PREC_F16X2", np);
+    }
     if (sub_snps <= 0) {
         // Whole blocks per kernel pair.  Measured on MI355X (tools/microbench.hip E2): re-reading a sub-block that
         // was just streamed (Infinity Cache) is at most ~20 % faster than HBM, while short launches lose more than
