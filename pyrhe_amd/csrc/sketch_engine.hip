@@ -406,11 +406,6 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     if (dom && ((e->n_sketch && !out_dom) || (e->n_norm && !norm_dom))) return fail(PYRHE_EINVAL, "dominance outputs incomplete");
     hipStream_t caller = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(e->device));
-    // int8 GEMM 2 (K = 64 SNPs per step, three int32 accumulator sets): correct (agrees with the fp16 hi+lo form to
-    // 4e-10 on sigma^2) but measured SLOWER at N=500k -- 40.4 ms vs 32.9 ms per pass: 468 registers pin it to one wave
-    // per SIMD and the 16x16 crumb transpose costs 240 v_perm/v_and per step.  Kept opt-in (PYRHE_G2_I8=1).
-    static const bool g2i8_env = getenv("PYRHE_G2_I8") && atoi(getenv("PYRHE_G2_I8")) != 0;
-    const bool g2i8 = g2i8_env && e->i8 && e->nto == 1 && e->n_sketch > 0 && !dom;
     // Serial mode (default): everything goes to the caller's stream, no events.  Pipelined mode: private streams A
     // (GEMM 1 + mid kernels) and B (GEMM 2), ordered against the caller's stream by events.
     const bool piped = e->pipeline && !dom;
@@ -431,14 +426,14 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     const int ncol_p = 16 * (e->i8 ? e->nt8 : e->ntl);       // values (fp16 form) / packed int32 slots (int8 form) per entry of P
     const int64_t sk_stride = (int64_t)e->n_sketch * e->n_pad;
     const float pscale = e->exact ? 1.0f : 16777216.0f;
-    const int kstep = g2i8 ? 64 : 32;
+    const int kstep = 32;
     // limb-packed int8 GEMM 2 (see gemm2_i8p_kernel): segment mode, <= 10 sketch columns, additive view
     static const bool g2p_off = getenv("PYRHE_G2_PACKED") && atoi(getenv("PYRHE_G2_PACKED")) == 0;
-    const bool g2p_ok = !g2p_off && e->i8 && e->parts == 2 && e->n_sketch >= 1 && e->n_sketch <= 2 * kI8pCols && !dom && !g2i8;
+    const bool g2p_ok = !g2p_off && e->i8 && e->parts == 2 && e->n_sketch >= 1 && e->n_sketch <= 2 * kI8pCols && !dom;
     const int g2p_ng = e->n_sketch <= kI8pCols ? 1 : 2;        // column groups of 10 = pairs of A tiles
     // RHE_DOM (per-list flow, three GEMM 2 launches per list, the third under the [g == 2] view): the packed kernel as a
     // one-segment launch, for cohorts whose sample range alone fills the chip; lists go in pieces of <= 16384 entries
-    const bool g2p_dom = !g2p_off && e->i8 && e->parts == 2 && dom && !g2i8 && e->n_sketch >= 1 && e->n_sketch <= kI8pCols &&
+    const bool g2p_dom = !g2p_off && e->i8 && e->parts == 2 && dom && e->n_sketch >= 1 && e->n_sketch <= kI8pCols &&
                          e->n_pad >= 192 * 1024;
 
     if (dom && !e->dom_ws) {
@@ -535,11 +530,6 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 const unsigned gridp = (unsigned)std::max<int64_t>(((int64_t)n_kb * 64 * g2p_ng + 255) / 256, (int64_t)tab.nseg * e->n_norm);
                 mid2_i8p_kernel<<<gridp, 256, 0, stream>>>(Wsrc, coef, e->n_sketch, 2 * g2p_ng, wmaxp, (int4v*)e->wfrag, e->corr, e->wscale, rows, e->rows32,
                                                            nsrc, ndst, e->n_norm, tab);
-            } else if (g2i8) {
-                const int64_t th = (int64_t)n_kb * 3 * 64;
-                mid2_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(Wsrc, coef, n, n_kb, e->n_sketch, wmaxp, (int4v*)e->wfrag, e->corr, e->wscale);
-                pad_rows_kernel<<<(n_kb * 64 + 255) / 256, 256, 0, stream>>>(rows, n, n_kb * 64, e->rows32);
-                if (ndst) norm_reduce_kernel<<<tab.nseg * e->n_norm, 256, 0, stream>>>(nsrc, e->n_norm, ndst, tab);
             } else if (e->parts == 2) mid2_kernel<2><<<grid, 256, 0, stream>>>(Wsrc, coef, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale, rows, e->rows32, nsrc, ndst, e->n_norm, tab);
             else mid2_kernel<1><<<grid, 256, 0, stream>>>(Wsrc, coef, e->n_sketch, e->nto, wmaxp, e->wfrag, e->corr, e->wscale, rows, e->rows32, nsrc, ndst, e->n_norm, tab);
         }
@@ -551,12 +541,11 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         // N=500k: the single-rounding pass is fastest with 512-sample waves even at 1 wave/SIMD, the hi+lo pass with
         // 256-sample waves at 2 waves/SIMD
         int iw = (e->nto == 1 && e->parts == 1 && e->n_pad >= 2048 * 160) ? 2 : 1;
-        if (g2i8) iw = 1;
         if (const char* ev = getenv("PYRHE_G2_IW")) iw = atoi(ev) == 2 && e->nto == 1 ? 2 : 1;
         const int gx = (int)((e->n_pad + 1024 * iw - 1) / (1024 * iw));
         int splits = gx >= 192 ? 1 : std::min(16, (512 + gx - 1) / gx);
         if (const char* ev = getenv("PYRHE_G2_SPLITS")) splits = atoi(ev);
-        splits = std::max(splits, (n_kb + (g2i8 ? 255 : 511)) / (g2i8 ? 256 : 512));   // row list of a K range lives in LDS: <= 64 KiB
+        splits = std::max(splits, (n_kb + 511) / 512);   // row list of a K range lives in LDS: <= 64 KiB
         splits = std::max(1, std::min(splits, n_kb));
         int kbps = (n_kb + splits - 1) / splits;
         splits = (n_kb + kbps - 1) / kbps;
@@ -606,13 +595,6 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             if (g2p_ng == 1) L2Q(1); else L2Q(2);
 #undef L2Q
 #undef L2P
-        } else if (g2i8) {
-            dim3 grid((unsigned)((e->n_pad + 1023) / 1024), splits);
-            const size_t lds = (size_t)kbps * 256;
-#define L2I(MISS_, VC_) gemm2_i8_kernel<MISS_, VC_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, n_kb, kbps, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, mode, partial)
-            if (e->vc) { if (fill) L2I(true, true); else L2I(false, true); }
-            else { if (fill) L2I(true, false); else L2I(false, false); }
-#undef L2I
         } else if (gv == 0) {
             if (e->parts == 2) { if (iw == 2) G2(1, 2, 2, true, 0); else if (e->nto == 1) G2(1, 2, 1, true, 0); else G2(2, 2, 1, true, 0); }
             else if (e->exact) { if (iw == 2) G2(1, 1, 2, true, 0); else if (e->nto == 1) G2(1, 1, 1, true, 0); else G2(2, 1, 1, true, 0); }
@@ -633,7 +615,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     // ---- several bins, additive sketch only: GEMM 1 once per chunk of the concatenated lists, per-bin work by segment
     // (a single list takes this flow too when the packed int8 GEMM 2 applies and the sample range alone fills the chip;
     // small cohorts keep the per-list flow, whose GEMM 2 can split K over workgroups)
-    const bool segflow = !dom && !g2i8 && (nbin > 1 || (g2p_ok && e->n_pad >= 192 * 1024));
+    const bool segflow = !dom && (nbin > 1 || (g2p_ok && e->n_pad >= 192 * 1024));
     if (segflow) {
         std::vector<char> touched(nbin, 0);
         for (int b = 0; b < nbin; ++b)
