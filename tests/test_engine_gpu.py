@@ -491,3 +491,35 @@ def test_large_cohort_paths_int8_vs_fp16(dev, coding, with_fill):
     for x, r in zip(outs["i8x3"], outs["f16x2"]):
         assert (x - r).abs().max().item() <= 1e-5 * r.abs().max().item()
     assert torch.equal(outs["i8x3"][0], outs["i8x3"][2])          # the additive sketch of the dominance call is the same kernel path
+
+
+def test_pipelined_streams_equal_serial(dev):
+    """pyrhe_engine_set_pipeline: GEMM 1 + mid kernels on one private stream, GEMM 2 on another, ordered by events (chunks of
+    one call, cut lists that accumulate, several calls back to back) -- the same bits as the serial mode (int8 engine:
+    integer atomics, fixed-order norm sums)."""
+    from pyrhe_amd import engine
+    n, m, k = 3000, 30000, 10
+    rng = np.random.default_rng(31)
+    packed = engine.synth_genotypes(m, n, 13, 0, dev)
+    lists = [np.sort(rng.choice(m, sz, replace=False)).astype(np.int32) for sz in (18000, 700, 9000, 25, 17000)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+    entries = torch.from_numpy(np.concatenate(lists)).to(dev)
+    res = []
+    for piped in (False, True):
+        eng = engine.SketchEngine(n, n, max_entries=m, precision="i8x3", device=dev, sub_snps=32768)
+        eng.set_pipeline(piped)
+        keep = eng.keep_vector([])
+        g = torch.Generator().manual_seed(8)
+        Z = torch.zeros((k, eng.n_pad), device=dev)
+        Z[:, :n] = torch.randn((k, n), generator=g).to(dev)
+        y = torch.zeros((2, eng.n_pad), device=dev)
+        y[:, :n] = torch.randn((2, n), generator=g).to(dev)
+        eng.set_rhs(Z, y, keep)
+        sk, nm, cs = eng.sketch_block(packed, entries, offs, want_colsum=True)
+        sk2, nm2, _ = eng.sketch_block(packed, entries, offs, out_sketch=sk.clone(), out_norm=nm.clone(), accumulate=True)
+        s1, n1, _ = eng.sketch_block(packed, entries[:offs[1]], [0, offs[1]])
+        torch.cuda.synchronize()
+        res.append([t.clone() for t in (sk, nm, cs, sk2, nm2, s1, n1)])
+        eng.close()
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
