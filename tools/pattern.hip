@@ -138,6 +138,8 @@ int main() {
         };
         run16(cols16_kernel<4, false, false>, 4, 4, false, "cols16: W=4, 16 rows/step, no barrier");
         run16(cols16_kernel<4, true, false>, 4, 4, false, "cols16: W=4, 16 rows/step, barrier every 2 steps (packed int8 kernel)");
+        run16(cols16_kernel<4, true, true>, 4, 4, true, "cols16: W=4, wave PAIRS read the same 64 B, barrier (useful bytes once)");
+        run16(cols16_kernel<4, true, true>, 4, 8, true, "cols16: W=4, wave PAIRS, 8 waves/WG, barrier");
         run16(cols16_kernel<8, true, false>, 8, 4, false, "cols16: W=8, barrier every 2 steps, distinct data per wave");
         run16(cols16_kernel<8, true, true>, 8, 4, true, "cols16: W=8, wave PAIRS read the same 128 B, barrier (useful bytes once)");
         run16(cols16_kernel<8, false, true>, 8, 4, true, "cols16: W=8, wave PAIRS read the same 128 B, no barrier");
