@@ -36,8 +36,12 @@ __device__ __forceinline__ uint32_t geno_values(uint32_t w, int fill) {
         return v;
     }
     if (!MISSING) return w;
-    const uint32_t m = w & (w >> 1) & 0x55555555u;          // 01 at the crumbs that hold 3
-    return fill == 0 ? w - m - (m << 1) : (fill == 1 ? w - (m << 1) : w - m);
+    // 3 (binary 11) -> fill: clear the low bit unless fill is 1, the high bit unless fill is 2.  The two masks depend on
+    // the row only (GEMM 1 hoists them out of its loop): shift, and, and, and, shift, xor3 per dword.
+    const uint32_t kl = fill == 1 ? 0u : 0x55555555u;
+    const uint32_t kh = fill == 2 ? 0u : 0x55555555u;
+    const uint32_t t = w & (w >> 1);                        // low bit of a crumb: it holds 3 (other bits: masked below)
+    return w ^ (t & kl) ^ ((t & kh) << 1);
 }
 
 // Two genotypes -> one register of two fp16 values.  Two variants:

@@ -373,12 +373,28 @@ class SketchRunner:
             self._entries_cache[key] = (torch.from_numpy(np.concatenate(ents).astype(np.int32)).to(self.device), np.asarray(offs, np.int64))
         return self._entries_cache[key]
 
+    def _block_fills(self, pass_index: int):
+        """Fill vectors (device float32, or None for a block without a missing call) of every local block for the draws of
+        ``pass_index`` (see _uniform_stream).  They depend on the seed, the keep mask and the genotypes only -- not on the
+        phenotype, not on how often a pass runs -- so the replay of NumPy's stream (it starts by re-drawing the N x k probe
+        matrix: 50 ms at N = 500k) is paid once per runner, not once per pass."""
+        if not hasattr(self, "_fills"):
+            self._fills = {}
+        if pass_index not in self._fills:
+            draw = self._uniform_stream(pass_index)
+            out = []
+            for j in range(self.j0, self.j1):
+                sj, ej = self.plan.range(j)
+                out.append(self._fill_for_block(j, draw(j, ej - sj)))      # one uniform per SNP, missing or not (base.py:266,285)
+            self._fills[pass_index] = out
+        return self._fills[pass_index]
+
     def sketch_local_blocks(self, out_sk, out_norm, pass_index: int = 0, after_block=None):
         """Enqueue the sketch of every local block: ``out_sk[p][jl]`` / ``out_norm[p][jl]`` receive the per-block
         outputs of engine pass p (``[nbin, n_sketch_p, n_pad]`` float32 / ``[nbin, n_norm_p]`` float64).  With a
         one-slot store (``recompute_pass2``) every block lands in slot 0 and ``after_block(jl_index, j)`` consumes it."""
         any_missing = bool(self._check_missing and self._ingest_stats()[1].any())
-        draw = self._uniform_stream(pass_index) if any_missing else None
+        block_fills = self._block_fills(pass_index) if any_missing else None
         one_slot = after_block is not None
         pipelined = [] if one_slot else [eng for eng in self.engs if hasattr(eng, "set_async")]
         for eng in pipelined:
@@ -403,8 +419,7 @@ class SketchRunner:
                     parts = []
                     for j in js:
                         sj, ej = self.plan.range(j)
-                        f = self._fill_for_block(j, draw(j, ej - sj))      # one uniform per SNP, missing or not (base.py:266,285)
-                        parts.append((f, ej - sj))
+                        parts.append((block_fills[j - self.j0], ej - sj))
                     if any(f is not None for f, _ in parts):      # blocks without a missing call need no fill path
                         fill = torch.cat([f if f is not None else torch.zeros(m_, dtype=torch.float32, device=self.device)
                                           for f, m_ in parts]) if len(parts) > 1 else parts[0][0]
@@ -976,15 +991,7 @@ class SketchRunner:
         ent, offs = self._entries(j)
         fill = None
         if self._check_missing and self._ingest_stats()[1].any():
-            if getattr(self, "_redraw", None) is None or self._redraw[0] > j:
-                self._redraw = [self.j0, self._uniform_stream(0)]
-            s, e = self.plan.range(j)
-            while self._redraw[0] < j:                    # blocks skipped since the last call still consume draws
-                s2, e2 = self.plan.range(self._redraw[0])
-                self._redraw[1](self._redraw[0], e2 - s2)
-                self._redraw[0] += 1
-            fill = self._fill_for_block(j, self._redraw[1](j, e - s))
-            self._redraw[0] = j + 1
+            fill = self._block_fills(0)[j - self.j0]
         if self.dom:
             outs = [self.engs[p].sketch_block_dom(self._block_rows(j), ent, offs, fill=fill) for p in range(self.n_pass)]
             return [o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], [o[3] for o in outs]
