@@ -467,7 +467,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     };
 
     // ---- GEMM 1 of one entry list, genotype view gv, into Pbuf (zeroed by the caller)
-    auto run_gemm1 = [&](int gv, const int32_t* rows, int n, float* Pbuf) {
+    auto run_gemm1 = [&](int gv, const int32_t* rows, int n, float* Pbuf, float* Pbuf2 = nullptr) {
         const int gx = (n + 255) / 256;
         const int g1_ch = (e->i8 && e->nt8 > 3) ? 1 : 2;  // 256-sample chunks per step (see gemm1_i8_kernel)
         const int n_steps = n_chunks / g1_ch;             // pitch is a multiple of 256 B = 4 chunks
@@ -484,10 +484,11 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         const int ua = splits > 1;
         if (e->i8) {
             const size_t lds = (size_t)2 * g1_ch * 4 * e->nt8 * 1024;
-#define G1I(NT_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua); \
-                                  else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua); } while (0)
+#define G1I(NT_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2); \
+                                  else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2); } while (0)
 #define G1J(NT_) do { if (gv == 0) { if (fill) G1I(NT_, true, 0); else G1I(NT_, false, 0); } \
-                      else { if (fill) G1I(NT_, true, 1); else G1I(NT_, false, 1); } } while (0)
+                      else if (gv == 1) { if (fill) G1I(NT_, true, 1); else G1I(NT_, false, 1); } \
+                      else { if (fill) G1I(NT_, true, 2); else G1I(NT_, false, 2); } } while (0)
             switch (e->nt8) {
                 case 1: G1J(1); break;
                 case 2: G1J(2); break;
@@ -710,7 +711,14 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             tab.kb0[1] = n_kb;
             tab.acc[0] = acc_now ? 1 : 0;
             { const int rcz = zero_ws(n); if (rcz) return rcz; }
-            run_gemm1(0, rows, n, e->P);
+            // int8 engine: one GEMM 1 launch (one read) for both genotype views; beyond four tiles twice the accumulators spill
+            const bool both_views = dom && e->i8 && e->nt8 <= 4;
+            if (both_views) {
+                HIPCHK(hipMemsetAsync(e->dom_ws, 0, e->dom_zero_bytes, stream));
+                run_gemm1(2, rows, n, e->P, e->P2);
+            } else {
+                run_gemm1(0, rows, n, e->P);
+            }
             {
                 ProfScope ps(e, stream, 1);
                 mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
@@ -729,8 +737,10 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             }
             if (dom) {
                 // ---- dominance: second GEMM 1 with the 2*[g==2] view, then two GEMM 2 launches into out_dom
-                HIPCHK(hipMemsetAsync(e->dom_ws, 0, e->dom_zero_bytes, stream));
-                run_gemm1(1, rows, n, e->P2);
+                if (!both_views) {
+                    HIPCHK(hipMemsetAsync(e->dom_ws, 0, e->dom_zero_bytes, stream));
+                    run_gemm1(1, rows, n, e->P2);
+                }
                 HIPCHK(hipMemsetAsync(e->corr, 0, 16 * kMaxTiles * sizeof(double), stream));
                 HIPCHK(hipMemsetAsync(e->wmax, 0, 16 * kMaxTiles * sizeof(uint32_t), stream));
                 {
