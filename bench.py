@@ -120,10 +120,13 @@ def main():
     t_gen = time.perf_counter()
     geno = eng_mod.synth_genotypes(r1 - r0, N, SYNTH_SEED, r0, dev)          # resident in HBM before timing
     if args.missing_rate > 0:                    # PLINK missing code 01 in the first call of random bytes, before the recode
-        gen = torch.Generator(device=dev).manual_seed(99)
-        for a in range(0, geno.shape[0], 4096):
-            part = geno[a:a + 4096]
-            hit = torch.rand(part.shape, device=dev, generator=gen) < args.missing_rate * 4
+        gen = torch.Generator(device=dev)
+        for a in range(r0 - r0 % 4096, r1, 4096):            # the pattern is a function of the GLOBAL row: same cohort on any rank count
+            gen.manual_seed(99 + a // 4096)
+            hit = torch.rand((4096, geno.shape[1]), device=dev, generator=gen) < args.missing_rate * 4
+            lo, hi = max(a, r0), min(a + 4096, r1)
+            part = geno[lo - r0:hi - r0]
+            hit = hit[lo - a:hi - a]
             part[hit] = (part[hit] & 0xFC) | 0x01
         del part, hit
     coding = os.environ.get("PYRHE_CODING", "value")
