@@ -26,7 +26,8 @@ def _last_json(out: str) -> dict:
     return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("extra", [[], ["--n-bin", "4", "--n-cov", "3"]])
+@pytest.mark.parametrize("extra", [[], ["--n-bin", "4", "--n-cov", "3"],
+                                   ["--n-bin", "2", "--n-cov", "2", "--missing-rate", "0.01", "--drop-indv", "37"]])
 def test_bench_two_ranks_equal_one_rank(extra):
     env = dict(os.environ, PYRHE_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + ARGS + extra, cwd=REPO, env=env, capture_output=True,
