@@ -160,3 +160,20 @@ def test_gemm_form_emulation_bounds_the_precision_modes():
         assert np.abs(A.T - ref).max() <= tol * np.abs(ref).max(), mode
         yx = float((V[:, p.k].astype(np.float64) ** 2).sum())
         assert abs(yx - z["ref_t0_yXXy_blocks"][0, 0]) <= 2 * tol * z["ref_t0_yXXy_blocks"][0, 0]
+
+
+def test_solve_all_equals_per_system_qr_and_keeps_error_behaviour():
+    """estimate.solve_all (one stacked QR + vectorised back-substitution) against the reference's per-system
+    scipy QR + solve_triangular (base.py:306-312); a singular system surfaces the same LinAlgError."""
+    from pyrhe_amd import estimate as est
+    rng = np.random.default_rng(3)
+    for n in (2, 3, 9, 17):
+        A = rng.normal(size=(101, n, n))
+        T = A @ A.transpose(0, 2, 1) + 0.1 * np.eye(n)
+        q = rng.normal(size=(101, n))
+        ref = np.array([est.solve_normal_equations(T[j], q[j].reshape(-1, 1)) for j in range(101)])
+        got = est.solve_all(T, q)
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert np.allclose(est.solve_all(T, q, "lstsq"), ref, rtol=1e-8)
+    with pytest.raises(np.linalg.LinAlgError):
+        est.solve_all(np.zeros((3, 2, 2)), np.ones((3, 2)))
