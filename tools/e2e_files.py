@@ -13,6 +13,12 @@ out = "/tmp/e2e"; os.makedirs(out, exist_ok=True); prefix = os.path.join(out, "c
 dev = torch.device("cuda:0")
 t0 = time.perf_counter()
 g = E.synth_genotypes(M, N, 7, 0, dev)
+if os.environ.get("MISSING"):                 # plant PLINK missing codes (01): the imputation path then runs in every pass
+    for a in range(0, M, 4096):
+        part = g[a:a + 4096]
+        hit = torch.rand(part.shape, device=dev) < float(os.environ["MISSING"]) * 4
+        part[hit] = (part[hit] & 0xFC) | 0x01
+    del part, hit
 rb = (N + 3) // 4
 with open(prefix + ".bed", "wb") as f:
     f.write(bytes([0x6C, 0x1B, 0x01]))
@@ -39,8 +45,12 @@ t0 = time.perf_counter()
 m = models.StreamingRHE(geno_file=prefix, annot_file=prefix + ".annot", pheno_file=prefix + ".pheno", cov_file=prefix + ".cov",
                         num_jack=100, num_random_vec=10, seed=0, device="cuda", log=log)
 torch.cuda.synchronize(); t1 = time.perf_counter()
+import cProfile, pstats
+pr0 = cProfile.Profile(); pr0.enable()
 res = m(trait=0)
-torch.cuda.synchronize(); t2 = time.perf_counter()
+torch.cuda.synchronize(); pr0.disable(); t2 = time.perf_counter()
+if os.environ.get("PROFILE_FIRST"):
+    pstats.Stats(pr0).sort_stats("cumulative").print_stats(28)
 print(f"construct (parse + upload + recode + engines): {t1 - t0:.2f} s;  trait (pass 1 + pass 2 + estimates): {t2 - t1:.2f} s")
 print("sigma", np.round(res["sigma_ests_total"], 5), "h2", np.round(res["h2_total"], 5))
 import cProfile, pstats
