@@ -60,28 +60,46 @@ def parse_args():
                          "(block statistics, replayed NumPy draws, fill values in both contractions) then runs in every pass")
     ap.add_argument("--drop-indv", type=int, default=0, help="cross-check aid: individuals without a phenotype (keep mask)")
     ap.add_argument("--dom", action="store_true", help="RHE_DOM: additive + dominance sketches (pyrhe_engine_sketch_block_dom)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="launch-shape knob of pyrhe_engine_set_option (pyrhe_amd.engine.OPTIONS), e.g. g1_workgroups=708; "
+                         "every value computes the same results")
+    ap.add_argument("--no-cross-check", action="store_true", help="skip the in-run i8x3 vs f16x2 comparison on three blocks")
     return ap.parse_args()
 
 
-def cpu_baseline(n_indv: int, k: int, n_snps: int) -> dict:
+def cpu_baseline(n_indv: int, k: int, n_blocks: int, block_snps: int, gpu_check=None) -> dict:
     """The oracle's reference-order pass-1 body (decode -> flip -> per-SNP impute loop -> standardize -> k float32
     GEMV pairs + yXXy, float64 accumulate; oracle/rhe_oracle.py restating base_streaming.py:85-104) on a bounded
-    sample of the same synthetic cohort, on this box's host cores."""
+    sample of the same synthetic cohort -- its first ``n_blocks`` x ``block_snps`` SNPs as ``n_blocks`` jackknife
+    blocks -- on this box's host cores.  SURVEY 8(d) planned 100 x 200 SNPs; at the ~85 SNPs/s this port reaches at
+    N = 500k that is four minutes, so the default sample is 10 x 200 (the metric is linear in the SNP count).
+    ``gpu_check(j, oracle_block)``: the caller's comparison of the HIP engine's sketch of the same block with the
+    oracle's (the oracle is the checker here, never the thing measured on the GPU side); its worst relative
+    deviations are reported beside the baseline."""
     from oracle import plink, synth
     from oracle import rhe_oracle as O
     torch.set_num_threads(max(1, os.cpu_count() or 1))
+    n_snps = n_blocks * block_snps
     g = synth.synth_rows(SYNTH_SEED, 0, n_snps, n_indv)
     packed = plink.encode_bed_rows(g)
     rng = np.random.default_rng(1)
     y = rng.normal(size=(n_indv, 1)); y -= y.mean()
-    p = O.Problem(packed=packed, n_indv_orig=n_indv, annot=np.ones((n_snps, 1), np.int64), pheno=y, n_jack=1, k=k, seed=0)
+    p = O.Problem(packed=packed, n_indv_orig=n_indv, annot=np.ones((n_snps, 1), np.int64), pheno=y, n_jack=n_blocks, k=k, seed=0)
     p.Z = O.make_probe_vectors(0, n_indv, k)
-    t0 = time.perf_counter()
-    O.sketch_block(p, 0, reseed=False)
-    dt = time.perf_counter() - t0
-    return {"value": n_snps / dt, "unit": "SNPs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"pass-1 body of the reference-order oracle on {n_snps} SNPs x N={n_indv}, k={k}, one block, "
-                      f"torch CPU float32 GEMV pairs ({dt:.1f} s)"}
+    dt, worst = 0.0, {}
+    for j in range(n_blocks):
+        t0 = time.perf_counter()
+        blk = O.sketch_block(p, j, reseed=False)
+        dt += time.perf_counter() - t0
+        if gpu_check is not None:
+            for key, v in gpu_check(j, blk).items():
+                worst[key] = max(worst.get(key, 0.0), float(v))
+    out = {"value": n_snps / dt, "unit": "SNPs/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"pass-1 body of the reference-order oracle on the first {n_blocks} x {block_snps} SNPs x N={n_indv}, k={k} "
+                     f"(SURVEY 8d planned 100 x 200; bounded to keep the default run short), torch CPU float32 GEMV pairs ({dt:.1f} s)"}
+    if worst:
+        out["gpu_vs_oracle"] = worst
+    return out
 
 
 def main():
@@ -128,7 +146,7 @@ def main():
             part = geno[lo - r0:hi - r0]
             hit = hit[lo - a:hi - a]
             part[hit] = (part[hit] & 0xFC) | 0x01
-        del part, hit
+            del part, hit
     coding = os.environ.get("PYRHE_CODING", "value")
     if coding == "value":
         eng_mod.recode_rows(geno, "value")       # the load-time recode of the product path (models.py), outside the timing
@@ -138,9 +156,18 @@ def main():
     keep_idx = np.setdiff1d(np.arange(N), np.asarray(dropped, dtype=np.int64))
     Nk = len(keep_idx)                           # individuals with a phenotype: every per-individual input has this length
     check_missing = args.missing_rate > 0
-    engine = eng_mod.SketchEngine(N, Nk, max_entries=engine_capacity(plan), precision=args.precision, device=dev,
-                                  sub_snps=args.sub_snps or engine_capacity(plan))
-    engine.set_coding(coding)
+    cap = args.sub_snps or engine_capacity(plan)
+    opts = [(o.split("=", 1)[0], int(o.split("=", 1)[1])) for o in args.opt]
+
+    def make_engine(precision, capacity=None):
+        e_ = eng_mod.SketchEngine(N, Nk, max_entries=capacity or engine_capacity(plan), precision=precision, device=dev,
+                                  sub_snps=capacity or cap)
+        e_.set_coding(coding)
+        for name, val in opts:
+            e_.set_option(name, val)
+        return e_
+
+    engine = make_engine(args.precision)
     np.random.seed(0)
     Z = np.random.randn(Nk, k)                                              # NumPy legacy stream, seed 0
     y = np.random.default_rng(1).normal(size=Nk); y -= y.mean()
@@ -148,8 +175,7 @@ def main():
         # heritable phenotype for the parity check between precision modes: y = a * (K r) + b * noise, K r = X X^T r / M
         r = np.random.default_rng(7).normal(size=(Nk, 1))
         # always built in the parity-safe mode, so that every --precision is verified on the SAME phenotype
-        eng_y = eng_mod.SketchEngine(N, Nk, max_entries=engine_capacity(plan), precision="i8x3", device=dev, sub_snps=args.sub_snps or engine_capacity(plan))
-        eng_y.set_coding(coding)
+        eng_y = make_engine("i8x3")
         rr = SketchRunner(eng_y, geno, plan, (j0, j1), n_orig=N, missing_indv=dropped, Z=r, seed=0, streaming=True)
         rr.begin_trait(y, check_missing=check_missing)
         rr.pass1()
@@ -167,14 +193,11 @@ def main():
         env = np.random.default_rng(3).integers(0, 2, size=Nk).astype(np.float64)     # Bernoulli(0.5)
     # one engine per pass over the genotypes: the column groups (Z, UZ, e.Z, e.UZ of k columns each) that do not fit one
     # engine's 30 right-hand columns go to further engines (k = 10: one, or two for GxE + covariates)
-    engines = [engine]
-    for _ in range(n_engines_needed(k, cov is not None, bool(args.genie)) - 1):
-        engines.append(eng_mod.SketchEngine(N, Nk, max_entries=engine_capacity(plan), precision=args.precision, device=dev,
-                                            sub_snps=args.sub_snps or engine_capacity(plan)))
-        engines[-1].set_coding(coding)
+    n_eng = n_engines_needed(k, cov is not None, bool(args.genie))
+    engines = [engine] + [make_engine(args.precision) for _ in range(n_eng - 1)]
+    compat = "fixed" if (cov is not None or args.genie) else "reference"
     runner = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, env=env,
-                          genie_model=args.genie, seed=0, streaming=True, dom=args.dom,
-                          compat="fixed" if (cov is not None or args.genie) else "reference")
+                          genie_model=args.genie, seed=0, streaming=True, dom=args.dom, compat=compat)
     runner.begin_trait(y, check_missing=check_missing)      # the generator itself emits no missing calls (contract of synth_kernel)
 
     def barrier():
@@ -185,21 +208,27 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_passes(rn):
+        barrier()
+        t0_ = time.perf_counter()
+        for _ in range(args.steps):
+            rn.pass1()
+        barrier()
+        dt_ = time.perf_counter() - t0_
+        if world > 1:
+            t_ = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            dt_ = float(t_.item())
+        return dt_
+
     for _ in range(args.warmup):
         runner.pass1()
     barrier()
     engine.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.pass1()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed_passes(runner)
     prof = engine.profile_read()
     engine.profile(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    path = engine.last_path()                    # the kernels the timed passes launched (pyrhe_engine_info 6..8)
     ms_per_step = dt / args.steps * 1e3
     value = M * args.steps / dt
 
@@ -209,28 +238,32 @@ def main():
     g1, g2 = prof["gemm1_ms"], prof["gemm2_ms"]
     dom = "gemm2_kernel" if g2 >= g1 else "gemm1_kernel"
     dom_ms = max(g1, g2)
-    # which kernels ran (pyrhe_amd/csrc/sketch_engine.hip): int8 GEMM 1 under i8x3 / i8f16; the limb-packed int8 GEMM 2
-    # under i8x3 with <= 20 sketch columns, the fp16 GEMM 2 otherwise
-    g1_name = "gemm1_i8_kernel" if args.precision in ("i8x3", "i8f16") else "gemm1_kernel"
-    g2_packed = args.precision == "i8x3" and 1 <= engine.n_sketch <= 20 and os.environ.get("PYRHE_G2_PACKED", "1") != "0"
-    g2_name = "gemm2_i8p_kernel" if g2_packed else "gemm2_kernel"
+    g1_i8 = path["gemm1"] >= 100
+    g1_name = f"gemm1_i8_kernel<{path['gemm1'] - 100}>" if g1_i8 else f"gemm1_kernel<{path['gemm1']}>"
+    g2_packed = path["gemm2"] in (11, 12)
+    g2_name = f"gemm2_i8p_kernel<{path['gemm2'] - 10}>" if g2_packed else "gemm2_kernel"
     dom_name = g2_name if dom == "gemm2_kernel" else g1_name
     bytes_per_launch = local_snps * row_bytes / launches                    # algorithmic bytes: ceil(N/4) per SNP
     achieved = bytes_per_launch / (dom_ms / launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md): the measured
-    # bytes per algorithmic byte of that kernel times this run's algorithmic bytes per launch, only when this run has the
-    # shape those passes were taken on (10 000-SNP blocks at N = 500 000, one bin)
-    traffic = None
-    try:
-        with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as fh:
-            tj = json.load(fh)
-        key = {"gemm1_kernel": "gemm1_i8_kernel" if g1_name == "gemm1_i8_kernel" else "gemm1_kernel_f16",
-               "gemm2_kernel": "gemm2_i8p_kernel" if g2_packed else
-                               ("gemm2_kernel_f16" if args.precision in ("f16", "i8f16") else "gemm2_kernel_f16x2")}[dom]
-        if N == tj["n_indv"] and M // jn == tj["block_snps"] and args.n_bin == 1:
-            traffic = int(tj["kernels"][key]["bytes_per_algorithmic_byte"] * bytes_per_launch)
-    except Exception:
-        traffic = None
+    # HBM bytes per launch: NOT a counter of this run.  It is the bytes-per-algorithmic-byte ratio of that kernel from the
+    # committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md; separate rocprofv3 --pmc runs) times this run's
+    # algorithmic bytes per launch, and only when this run has the shape those passes were taken on; `traffic_source` says
+    # which file, which commit and which shape.
+    traffic, traffic_source = None, None
+    for tf in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(REPO, "profiles", tf)) as fh:
+                tj = json.load(fh)
+            key = {"gemm1_kernel": "gemm1_i8_kernel" if g1_i8 else "gemm1_kernel_f16",
+                   "gemm2_kernel": "gemm2_i8p_kernel" if g2_packed else
+                                   ("gemm2_kernel_f16" if args.precision in ("f16", "i8f16") else "gemm2_kernel_f16x2")}[dom]
+            if N == tj["n_indv"] and M // jn == tj["block_snps"] and args.n_bin == 1 and key in tj["kernels"]:
+                traffic = int(tj["kernels"][key]["bytes_per_algorithmic_byte"] * bytes_per_launch)
+                traffic_source = (f"profiles/{tf}@{tj.get('commit', 'r01')}: separate --pmc passes at N={tj['n_indv']}, "
+                                  f"M={tj.get('n_snp', '?')}, jn={tj.get('jn', '?')}, ratio x this run's algorithmic bytes")
+                break
+        except Exception:
+            continue
     # matrix-core work of the dominant kernel as issued (16-column tiles, all limbs / parts), beside the byte roofline:
     # (the fp16 GEMM 2 is bound by instruction issue; the packed int8 GEMM 2 and GEMM 1 by HBM)
     n_pad = engine.n_pad
@@ -238,23 +271,21 @@ def main():
     tiles_out = max(1, (engine.n_sketch + 15) // 16)
     rows_per_launch = local_snps / launches
     if dom == "gemm2_kernel" and g2_packed:
-        mfma_ops = rows_per_launch * 2.0 * n_pad * 16 * (2 if engine.n_sketch <= 10 else 4)   # packed tiles of (digit, column) rows
+        mfma_ops = rows_per_launch * 2.0 * n_pad * 16 * (2 if path["gemm2"] == 11 else 4)      # packed tiles of (digit, column) rows
         mfma_peak = 5000.0                                                                     # int8 dense TOP/s
     elif dom == "gemm2_kernel":
         parts = 1 if args.precision in ("f16", "f16e", "i8f16") else 2
         mfma_ops, mfma_peak = rows_per_launch * 2.0 * n_pad * 16 * tiles_out * parts, 2500.0       # fp16 dense TFLOP/s
     else:
-        if g1_name == "gemm1_i8_kernel":       # packed (digit, column) rows: 3 per user column + the ones column
-            g1_tiles = (3 * (engine.n_sketch + engine.n_norm) + 1 + 15) // 16
-        else:
-            g1_tiles = tiles_in * (2 if args.precision == "f16x2" else 1)
+        g1_tiles = path["gemm1"] - 100 if g1_i8 else tiles_in * (2 if args.precision == "f16x2" else 1)
         mfma_ops = rows_per_launch * 2.0 * n_pad * 16 * g1_tiles
-        mfma_peak = 5000.0 if g1_name == "gemm1_i8_kernel" else 2500.0                             # int8 dense TOP/s
+        mfma_peak = 5000.0 if g1_i8 else 2500.0                                                    # int8 dense TOP/s
     mfma_tops = mfma_ops / (dom_ms / launches * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "mfma_tops_issued": round(mfma_tops, 1), "mfma_frac": round(mfma_tops / mfma_peak, 4),
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(dom_ms / launches, 4),
+                "kernels": {"gemm1": g1_name, "gemm2": g2_name, "segmented_flow": path["segmented"]},
                 "gemm1_ms_per_step": round(g1 / args.steps, 3), "gemm2_ms_per_step": round(g2 / args.steps, 3),
                 "mid_ms_per_step": round(prof["mid_ms"] / args.steps, 3),
                 "pass_frac": round(value * row_bytes / 1e9 / HBM_PEAK_GBS, 4)}
@@ -267,10 +298,17 @@ def main():
                                   + (f"StreamingGENIE {args.genie} (1 environment)" if args.genie else "StreamingRHE")
                                   + f" sketch pass, k={k} jn={jn}" + (f", {args.n_cov} covariates" if args.n_cov else ""),
                       "precision": args.precision, "coding": coding, "sub_snps": engine.sub_snps, "parallelism": f"blocks/{world}gpu",
-                      "gen_seconds": round(t_gen, 2)},
+                      "options": dict(opts), "gen_seconds": round(t_gen, 2)},
            "roofline": roofline}
 
-    if True:     # pass 2 + solves are cheap next to the sketch pass: always timed, reported beside the metric
+    def extra(name, fn):
+        """A leg beside the headline: its failure is reported in the line, it never sinks the measured number."""
+        try:
+            fn()
+        except Exception as ex:
+            out["config"][name] = {"failed": f"{type(ex).__name__}: {ex}"}
+
+    def leg_end_to_end():     # pass 2 + solves are cheap next to the sketch pass: always timed, reported beside the metric
         w = runner.pass2()                                                  # untimed: scratch allocation, BLAS thread start
         est.solve_all(w.T[:1], w.q[:1])
         barrier()
@@ -286,41 +324,98 @@ def main():
         if args.verify:
             out["config"]["sigma_total"] = [float(v) for v in sig[-1]]
             out["config"]["sigma_se"] = [float(v) for v in est.jackknife_se(sig[:-1], jn)]
+    extra("end_to_end", leg_end_to_end)
 
-    if not args.no_alt and not args.dom and args.precision in ("f16x2", "i8x3"):
-        # the same pass in the single-rounding mode (1 MFMA per fragment, subnormal unpack): reported beside the
-        # headline, never as `value` -- its sigma^2 error is ~2^-12/sqrt(N k), not bounded by 1e-5 at every size
-        del runner
-        engine.close()
-        engine = eng_mod.SketchEngine(N, Nk, max_entries=engine_capacity(plan), precision="f16", device=dev, sub_snps=args.sub_snps or engine_capacity(plan))
-        engine.set_coding(coding)
-        runner = SketchRunner(engine, geno, plan, (j0, j1), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, seed=0, streaming=True,
-                              compat="fixed" if cov is not None else "reference")
-        runner.begin_trait(y, check_missing=check_missing)
-        runner.pass1()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            runner.pass1()
-        barrier()
-        dt2 = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt2], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = float(t.item())
-        out["config"]["f16_single_rounding"] = {"value": M * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3,
-                                                "pass_frac": round(M * args.steps / dt2 * row_bytes / 1e9 / HBM_PEAK_GBS, 4)}
+    def leg_cross_check():
+        """The kernels behind `value` against the fp16 hi+lo kernels (other code in every stage) on the first three local
+        blocks: sigma^2 and jackknife SE of a 3-block run, same inputs."""
+        nb3 = min(3, j1 - j0)
+        if nb3 < 2 or args.dom:
+            return
+        s3, e3 = plan.range(j0)[0], plan.range(j0 + nb3 - 1)[1]
+        sub = BlockPlan(annot[s3:e3], nb3)
+        res = {}
+        for prec in (args.precision, "f16x2"):
+            engs = [make_engine(prec, engine_capacity(sub)) for _ in range(n_eng)]
+            rn = SketchRunner(engs, geno[s3 - r0:e3 - r0], sub, (0, nb3), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, env=env,
+                              genie_model=args.genie, seed=0, streaming=True, compat=compat, solo=True)
+            sysm = rn.run_trait(y, check_missing=check_missing)
+            sig = est.solve_all(sysm.T, sysm.q)
+            res[prec] = (sig[-1], np.asarray(est.jackknife_se(sig[:-1], nb3)), engs[0].last_path())
+            del rn
+            for e_ in engs:
+                e_.close()
+        a, b = res[args.precision], res["f16x2"]
+        out["config"]["cross_check"] = {"blocks": nb3, "against": "f16x2 kernels", "kernels": a[2],
+                                        "sigma_rel": float(np.max(np.abs(a[0] - b[0]) / np.abs(b[0]))),
+                                        "se_rel": float(np.max(np.abs(a[1] - b[1]) / np.abs(b[1])))}
+    if not args.no_cross_check and args.precision != "f16x2":
+        extra("cross_check", leg_cross_check)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_s = args.cpu_baseline_snps or int(min(20000, max(50, 400 * 500_000 / max(N, 1))))
+        # the CPU baseline leg; while the oracle has each block in hand it also checks the HIP engine's sketch of the same
+        # block (the headline kernels at the headline sample count) -- the oracle is the checker, never the product
+        n_s = args.cpu_baseline_snps or int(min(20000, max(200, 2000 * 500_000 / max(N, 1))))
+        bs = 200 if n_s >= 400 else n_s
+        nblk = max(1, n_s // bs)
+        chk_eng = make_engine(args.precision, max(bs, 1))
+        keep = chk_eng.keep_vector(dropped)
+        kt = torch.as_tensor(keep_idx, device=dev)
+
+        def padded(a2):                                      # [n, Nk] float64 -> [n, n_pad] float32 at the kept positions
+            t_ = torch.zeros((a2.shape[0], chk_eng.n_pad), dtype=torch.float32, device=dev)
+            t_[:, kt] = torch.from_numpy(np.ascontiguousarray(a2)).to(dev).to(torch.float32)
+            return t_
+        y_b = np.random.default_rng(1).normal(size=(N, 1)); y_b -= y_b.mean()       # the baseline's own phenotype (cpu_baseline)
+        can_check = not dropped and not args.missing_rate and r0 == 0 and (r1 - r0) >= nblk * bs
+        if can_check:
+            chk_eng.set_rhs(padded(make_probe(N, k).T), padded(y_b.T), keep)
+        ent = torch.arange(bs, dtype=torch.int32, device=dev)
+
+        def gpu_check(j, blk):
+            sk, nm, _ = chk_eng.sketch_block(geno[j * bs:(j + 1) * bs], ent, [0, bs])
+            got = sk[0, :, :N].double().cpu().numpy()
+            ref = blk.XXz[0]
+            return {"XXz_rel_of_block_max": np.abs(got - ref).max() / np.abs(ref).max(),
+                    "yXXy_rel": abs(float(nm[0, 0]) - blk.yXXy[0]) / abs(blk.yXXy[0])}
         try:
-            out["cpu_baseline"] = cpu_baseline(N, k, n_s)
+            out["cpu_baseline"] = cpu_baseline(N, k, nblk, bs, gpu_check if can_check else None)
+            if can_check:
+                out["cpu_baseline"]["gpu_kernels_checked"] = chk_eng.last_path()
         except Exception as ex:                                             # the baseline must never sink the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "SNPs/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
+        chk_eng.close()
+
+    def leg_alt():
+        # the same pass in the single-rounding mode (1 MFMA per fragment, subnormal unpack): reported beside the
+        # headline, never as `value` -- its sigma^2 error is ~2^-12/sqrt(N k), not bounded by 1e-5 at every size
+        nonlocal runner, engines
+        del runner
+        for e_ in engines:
+            e_.close()
+        engines = [make_engine("f16") for _ in range(n_eng)]
+        rn = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, env=env,
+                          genie_model=args.genie, seed=0, streaming=True, compat=compat)
+        rn.begin_trait(y, check_missing=check_missing)
+        rn.pass1()
+        dt2 = timed_passes(rn)
+        out["config"]["f16_single_rounding"] = {"value": M * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3,
+                                                "pass_frac": round(M * args.steps / dt2 * row_bytes / 1e9 / HBM_PEAK_GBS, 4)}
+        del rn
+    if not args.no_alt and not args.dom and args.precision in ("f16x2", "i8x3"):
+        extra("f16_single_rounding", leg_alt)
+    for e_ in engines:
+        e_.close()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def make_probe(n, k):
+    """The CPU baseline's probe vectors (oracle.make_probe_vectors: NumPy legacy stream, seed 0), for the GPU side of its check."""
+    np.random.seed(0)
+    return np.random.randn(n, k)
 
 
 if __name__ == "__main__":

@@ -72,9 +72,10 @@ int pyrhe_abi_version(void);
 
 /*
  * Create an engine on `device` for cohorts of `n_keep` retained samples stored with row pitch
- * `pitch` bytes.  `max_entries` bounds the SNPs of one (block, bin) list; `sub_snps` is the
- * sub-block size (SNPs per kernel triple; 0 = default sized so a sub-block stays in the 256 MiB
- * Infinity Cache between the two contractions).
+ * `pitch` bytes.  `max_entries` bounds the SNPs of one (block, bin) list; `sub_snps` is the number of
+ * entries one kernel triple (GEMM 1, mid, GEMM 2) takes (0 = 16384: whole blocks per launch -- measured,
+ * re-reading a just-streamed sub-block from the Infinity Cache gains less than short launches lose).
+ * On failure nothing stays allocated.
  * Replaces: Base._init_device / to_tensor device placement (pyrhe/src/base/base.py:195-206,
  * pyrhe/src/util/mat_mul.py:4-15).   Synchronous (allocates).
  */
@@ -202,6 +203,18 @@ int pyrhe_engine_loo_dots_multi(pyrhe_engine_t* e, const pyrhe_row_t* x, int nx,
                                 int n_batch, double* out_sub, double* out_flat, double* out_self, void* stream);
 
 /*
+ * out[r][:] = W (Q (W^T x[r][:])) for n_rows rows of n elements: the covariate projector U = W Q W^T of
+ * Base._compute_UXXz (pyrhe/src/base/base.py:407-408), applied to the whole-data XXz rows in pass 1
+ * (pyrhe/src/models/rhe/streaming_rhe.py:18-21).  Float32 semantics like the reference's mat_mul chain (operands cast to
+ * float32, each of the three products rounded to float32 once; inner sums in float64, fixed order: deterministic).
+ * x / out: device float64 [n_rows][n] (may not alias); Wt: device float [c][n] = W transposed, zero at dropped and padding
+ * samples; Q: device float [c][c] row-major = pinv(W^T W); 1 <= c <= 64.   Asynchronous on `stream`; uses the engine's
+ * scratch (one stream per engine, as pyrhe_engine_loo_dots).
+ */
+int pyrhe_engine_apply_projector(pyrhe_engine_t* e, const double* x, int64_t n_rows, int64_t n, const float* Wt,
+                                 const float* Q, int c, double* out, void* stream);
+
+/*
  * Genotype coding of the packed buffers.  PLINK (default): the .bed body as it is.  VALUE: every 2-bit field holds the
  * allele-2 count itself (00->0, 10->1, 11->2) and 3 for a missing call: the kernels then skip the three-instruction
  * code -> count conversion they otherwise pay per dword in both contractions of both passes (-8 % GEMM 2 time).
@@ -230,8 +243,25 @@ int pyrhe_decode_rows(const uint8_t* packed, int64_t n_rows, int64_t pitch, floa
 int pyrhe_synth_genotypes(uint8_t* packed, int64_t n_rows, int64_t pitch, int64_t n_samples,
                           uint64_t seed, int64_t row0, void* stream);
 
-/* engine introspection: 0 n_pad, 1 sub_snps, 2 n_tiles_in, 3 n_sketch, 4 n_norm, 5 workspace bytes */
+/* engine introspection: 0 n_pad, 1 sub_snps, 2 n_tiles_in, 3 n_sketch, 4 n_norm, 5 workspace bytes;
+ * which kernels the LAST sketch call launched (so a parity test can assert the path it checked is the path it meant):
+ *   6 GEMM 1: 100 + tiles for gemm1_i8_kernel<tiles>, tiles for gemm1_kernel<tiles> (fp16), 0 before any call
+ *   7 GEMM 2: 11 / 12 gemm2_i8p_kernel<NG = 1 / 2>, 1 gemm2_kernel (fp16 hi+lo or single), 0 none (no sketch columns)
+ *   8 flow  : 1 segmented (one GEMM 1 over the concatenated lists, GEMM 2 by segment), 0 one kernel triple per list */
 int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
+
+/*
+ * Launch-shape knobs (explicit setters; the library reads no environment variables).  Every value computes the same
+ * results; they exist for the measurements of DESIGN.md 3.4 and for tests that must pin a kernel path.
+ */
+#define PYRHE_OPT_G1_WORKGROUPS 1 /* target workgroups per GEMM 1 launch (sample-range splits follow); default 1536 */
+#define PYRHE_OPT_G2_PACKED 2     /* 0: never take the limb-packed int8 GEMM 2 (fp16 hi+lo instead); default 1    */
+#define PYRHE_OPT_G2_IW 3         /* fp16 GEMM 2: dwords per lane per row (1 / 2); 0 = automatic                    */
+#define PYRHE_OPT_G2_SPLITS 4     /* fp16 GEMM 2, per-list flow: K splits over workgroups; 0 = automatic           */
+#define PYRHE_OPT_DOTS_GENERIC 5  /* 1: pyrhe_engine_loo_dots always takes the register-tiled generic kernel        */
+#define PYRHE_OPT_G1_SPLIT_MAJOR 6 /* 1: GEMM 1 grid with the sample split as the fast index (co-resident workgroups
+                                      share rows); default 0                                                        */
+int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t value);
 
 /* name + average device time (ms, from hipEvents on the launch stream) of the kernels of the last
  * pyrhe_engine_sketch_block call made while profiling was enabled; see pyrhe_engine_profile(). */

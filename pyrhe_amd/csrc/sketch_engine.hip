@@ -8,9 +8,10 @@
 // mu_s = mean, d_s = 1/sqrt(mu_s (1 - mu_s/2)):
 //     X^T R = D (G^T R - mu (1^T R))          GEMM 1  (reduce over samples)   + rank-1 correction
 //     X  V  = G (D V) - 1 (mu^T D V)          GEMM 2  (reduce over SNPs)      + rank-1 correction
-// G is decoded in registers (0/1/2 are exact in int8 and fp16).  Default precision (i8x3): GEMM 1 on
-// v_mfma_i32_16x16x64_i8 with R as three int8 limbs and exact int32 accumulation, GEMM 2 on
-// v_mfma_f32_16x16x32_f16 with W = D V as a hi+lo fp16 pair; the fp16 forms of GEMM 1 serve f16x2 / f16.
+// G is decoded in registers (0/1/2 are exact in int8 and fp16).  Default precision (i8x3): both contractions on
+// v_mfma_i32_16x16x64_i8 with R and W = D V as three balanced radix-256 int8 digits per column and exact int32
+// accumulation (gemm1_i8_kernel, gemm2_i8p_kernel: <= 20 sketch columns, segmented flow); the fp16 kernels
+// (v_mfma_f32_16x16x32_f16, hi+lo pair or one rounding) serve f16x2 / f16 and the shapes the packed GEMM 2 does not take.
 //
 // Files: this one = engine state, launch logic, C ABI; sketch_common.h = decode / unpack helpers + segment table;
 // kernels_prep.inc, kernels_gemm1.inc, kernels_mid.inc, kernels_gemm2.inc, kernels_util.inc, kernels_dots.inc = kernels.
@@ -80,7 +81,7 @@ struct pyrhe_engine {
     int64_t n_keep = 0, pitch = 0, n_pad = 0, max_entries = 0, sub_snps = 0;
     int precision = 0, parts = 1;
     bool exact = false;   // exact (normal-number) genotype unpack instead of the 1-op subnormal unpack
-    bool i8 = false;      // GEMM 1 on int8 limbs (precision i8x3); GEMM 2 then runs the hi+lo fp16 form
+    bool i8 = false;      // int8 digit kernels (precision i8x3: GEMM 1 always, GEMM 2 where the packed kernel applies)
     bool vc = false;      // the caller's packed buffers hold the 2-bit VALUE code (pyrhe_recode_rows), not PLINK codes
     int n_sketch = 0, n_norm = 0, n_user = 0, ntl = 0, nto = 0, nt8 = 0;
     bool rhs_set = false;
@@ -138,22 +139,37 @@ struct pyrhe_engine {
     std::vector<Ev> evs;
     std::vector<hipEvent_t> pool;   // events are created once and reused across profiled passes
     size_t pool_used = 0;
+    bool prof_failed = false;       // an event could not be created: the profile of this pass is void (profile_read says so)
     hipEvent_t take_event() {
         if (pool_used == pool.size()) {
-            hipEvent_t ev;
-            (void)hipEventCreate(&ev);
+            hipEvent_t ev = nullptr;
+            if (hipEventCreate(&ev) != hipSuccess) { prof_failed = true; return nullptr; }
             pool.push_back(ev);
         }
         return pool[pool_used++];
     }
     size_t total_bytes = 0;
+    // launch-shape knobs (pyrhe_engine_set_option); every value computes the same results
+    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0;
+    // kernels of the last sketch call (pyrhe_engine_info 6..8)
+    int last_g1 = 0, last_g2 = 0, last_flow = 0;
 };
 
 static constexpr int kMaxTiles = 2;  // 32 logical columns
 // Two-stream overlap of GEMM 1 (next sub-block) with GEMM 2 (current): measured +3.5 % at N=500k (the two kernels
 // mostly time-share the CUs), at the price of per-kernel timings that include the contention.  Off by default;
-// PYRHE_PIPELINE=1 or pyrhe_engine_set_pipeline(e, 1) turns it on.
-static bool e_pipeline_default = false;
+// pyrhe_engine_set_pipeline(e, 1) turns it on.
+
+// Allocation failures inside pyrhe_engine_create: release everything made so far (destroy takes a half-built engine).
+#define HIPCHK_CREATE(expr)                                                                       \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            (void)pyrhe_engine_destroy(e);                                                        \
+            return fail((int)_e, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                        __LINE__);                                                                \
+        }                                                                                         \
+    } while (0)
 
 extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, int64_t max_entries, int precision,
                                    int64_t sub_snps, pyrhe_engine_t** out) {
@@ -167,9 +183,9 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     if (max_entries <= 0) return fail(PYRHE_EINVAL, "max_entries must be positive");
     HIPCHK(hipSetDevice(device));
     auto* e = new pyrhe_engine();
-    if (const char* ev = getenv("PYRHE_PIPELINE")) e_pipeline_default = atoi(ev) != 0;
+    e->sets[0] = e->sets[1] = pyrhe_engine::WorkSet{};
     e->device = device;
-    e->pipeline = e_pipeline_default;
+    e->pipeline = false;
     e->n_keep = n_keep;
     e->pitch = pitch;
     e->n_pad = 4 * pitch;
@@ -195,12 +211,12 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     e->max_entries = max_entries;
     const int ncolmax = 16 * kMaxTiles;
     e->rfrag_bytes = (size_t)e->n_pad * ncolmax * e->parts * sizeof(_Float16);
-    HIPCHK(hipMalloc(&e->rfrag, e->rfrag_bytes));
-    HIPCHK(hipMalloc(&e->rscale, ncolmax * sizeof(float)));
-    HIPCHK(hipMalloc(&e->csum, ncolmax * sizeof(double)));
-    HIPCHK(hipMalloc(&e->colmax, ncolmax * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&e->keepmask, e->n_pad / 16 * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&e->keep, e->n_pad * sizeof(float)));
+    HIPCHK_CREATE(hipMalloc(&e->rfrag, e->rfrag_bytes));
+    HIPCHK_CREATE(hipMalloc(&e->rscale, ncolmax * sizeof(float)));
+    HIPCHK_CREATE(hipMalloc(&e->csum, ncolmax * sizeof(double)));
+    HIPCHK_CREATE(hipMalloc(&e->colmax, ncolmax * sizeof(uint32_t)));
+    HIPCHK_CREATE(hipMalloc(&e->keepmask, e->n_pad / 16 * sizeof(uint32_t)));
+    HIPCHK_CREATE(hipMalloc(&e->keep, e->n_pad * sizeof(float)));
     // workspace
     const size_t S = (size_t)sub_snps;
     size_t off = 0;
@@ -221,8 +237,8 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     e->ws_bytes = off;
     for (int i = 0; i < 2; ++i) {
         uint8_t* base = nullptr;
-        HIPCHK(hipMalloc(&base, e->ws_bytes));
-        HIPCHK(hipMemset(base, 0, e->ws_bytes));
+        HIPCHK_CREATE(hipMalloc(&base, e->ws_bytes));
+        HIPCHK_CREATE(hipMemset(base, 0, e->ws_bytes));
         pyrhe_engine::WorkSet& w = e->sets[i];
         w.base = base;
         w.P = (float*)(base + oP);
@@ -234,15 +250,15 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
         w.wscale = (float*)(base + oWscale);
         w.wfrag = (half8*)(base + oWfrag);
         w.rows32 = (int32_t*)(base + oRows);
-        HIPCHK(hipEventCreateWithFlags(&e->evA[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&e->evB[i], hipEventDisableTiming));
+        HIPCHK_CREATE(hipEventCreateWithFlags(&e->evA[i], hipEventDisableTiming));
+        HIPCHK_CREATE(hipEventCreateWithFlags(&e->evB[i], hipEventDisableTiming));
     }
     e->use_set(0);
-    HIPCHK(hipStreamCreateWithFlags(&e->sA, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&e->sB, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&e->evIn, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&e->evDoneA, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&e->evDoneB, hipEventDisableTiming));
+    HIPCHK_CREATE(hipStreamCreateWithFlags(&e->sA, hipStreamNonBlocking));
+    HIPCHK_CREATE(hipStreamCreateWithFlags(&e->sB, hipStreamNonBlocking));
+    HIPCHK_CREATE(hipEventCreateWithFlags(&e->evIn, hipEventDisableTiming));
+    HIPCHK_CREATE(hipEventCreateWithFlags(&e->evDoneA, hipEventDisableTiming));
+    HIPCHK_CREATE(hipEventCreateWithFlags(&e->evDoneB, hipEventDisableTiming));
     e->total_bytes = 2 * e->ws_bytes + e->rfrag_bytes + e->n_pad * 4 + e->n_pad / 4;
     *out = e;
     return PYRHE_OK;
@@ -277,6 +293,9 @@ extern "C" int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what) {
         case 3: return e->n_sketch;
         case 4: return e->n_norm;
         case 5: return (int64_t)e->total_bytes;
+        case 6: return e->last_g1;
+        case 7: return e->last_g2;
+        case 8: return e->last_flow;
         default: return -1;
     }
 }
@@ -349,11 +368,11 @@ struct ProfScope {
         if (e->profile) {
             a = e->take_event();
             b = e->take_event();
-            (void)hipEventRecord(a, s);
+            if (a && b) (void)hipEventRecord(a, s);
         }
     }
     ~ProfScope() {
-        if (e->profile) {
+        if (e->profile && a && b) {
             (void)hipEventRecord(b, s);
             e->evs.push_back({kind, a, b});
         }
@@ -428,7 +447,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     const float pscale = e->exact ? 1.0f : 16777216.0f;
     const int kstep = 32;
     // limb-packed int8 GEMM 2 (see gemm2_i8p_kernel): segment mode, <= 10 sketch columns, additive view
-    static const bool g2p_off = getenv("PYRHE_G2_PACKED") && atoi(getenv("PYRHE_G2_PACKED")) == 0;
+    const bool g2p_off = e->opt_g2_packed == 0;
     const bool g2p_ok = !g2p_off && e->i8 && e->parts == 2 && e->n_sketch >= 1 && e->n_sketch <= 2 * kI8pCols && !dom;
     const int g2p_ng = e->n_sketch <= kI8pCols ? 1 : 2;        // column groups of 10 = pairs of A tiles
     // RHE_DOM (per-list flow, three GEMM 2 launches per list, the third under the [g == 2] view): the packed kernel as a
@@ -471,7 +490,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         const int gx = (n + 255) / 256;
         const int g1_ch = (e->i8 && e->nt8 > 3) ? 1 : 2;  // 256-sample chunks per step (see gemm1_i8_kernel)
         const int n_steps = n_chunks / g1_ch;             // pitch is a multiple of 256 B = 4 chunks
-        static const int g1_wgs = getenv("PYRHE_G1_WGS") ? atoi(getenv("PYRHE_G1_WGS")) : 1536;   // target workgroups per launch
+        const int g1_wgs = e->opt_g1_wgs;                 // target workgroups per launch
         int splits = (g1_wgs + gx - 1) / gx;
         splits = std::max(1, std::min(splits, n_steps / 4 > 0 ? n_steps / 4 : 1));
         int cps = (n_steps + splits - 1) / splits;        // steps per split, even (n_steps is even)
@@ -480,12 +499,14 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         float* saveP = e->P;
         e->P = Pbuf;
         ProfScope ps(e, stream, 0);
-        dim3 grid(gx, splits);
+        const int sm = e->opt_g1_split_major ? 1 : 0;      // grid order: which of (row group, sample split) is the fast index
+        dim3 grid(sm ? splits : gx, sm ? gx : splits);
         const int ua = splits > 1;
+        e->last_g1 = e->i8 ? 100 + e->nt8 : e->ntl;
         if (e->i8) {
             const size_t lds = (size_t)2 * g1_ch * 4 * e->nt8 * 1024;
-#define G1I(NT_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2); \
-                                  else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2); } while (0)
+#define G1I(NT_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm); \
+                                  else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm); } while (0)
 #define G1J(NT_) do { if (gv == 0) { if (fill) G1I(NT_, true, 0); else G1I(NT_, false, 0); } \
                       else if (gv == 1) { if (fill) G1I(NT_, true, 1); else G1I(NT_, false, 1); } \
                       else { if (fill) G1I(NT_, true, 2); else G1I(NT_, false, 2); } } while (0)
@@ -542,10 +563,10 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         // N=500k: the single-rounding pass is fastest with 512-sample waves even at 1 wave/SIMD, the hi+lo pass with
         // 256-sample waves at 2 waves/SIMD
         int iw = (e->nto == 1 && e->parts == 1 && e->n_pad >= 2048 * 160) ? 2 : 1;
-        if (const char* ev = getenv("PYRHE_G2_IW")) iw = atoi(ev) == 2 && e->nto == 1 ? 2 : 1;
+        if (e->opt_g2_iw) iw = e->opt_g2_iw == 2 && e->nto == 1 ? 2 : 1;
         const int gx = (int)((e->n_pad + 1024 * iw - 1) / (1024 * iw));
         int splits = gx >= 192 ? 1 : std::min(16, (512 + gx - 1) / gx);
-        if (const char* ev = getenv("PYRHE_G2_SPLITS")) splits = atoi(ev);
+        if (e->opt_g2_splits > 0) splits = e->opt_g2_splits;
         splits = std::max(splits, (n_kb + 511) / 512);   // row list of a K range lives in LDS: <= 64 KiB
         splits = std::max(1, std::min(splits, n_kb));
         int kbps = (n_kb + splits - 1) / splits;
@@ -577,6 +598,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             mode = acc_now ? 1 : 0;
         }
         ProfScope ps(e, sB2, 2);
+        e->last_g2 = ((g2p_dom && segmode) || (g2p_ok && segmode && gv == 0)) ? (g2p_dom && segmode ? 11 : 10 + g2p_ng) : 1;
 #define G2(NTO_, PARTS_, IW_, EX_, GV_) launch_gemm2<NTO_, PARTS_, IW_, EX_, GV_>(e, packed, n_kb, kbps, splits, fill, outp, mode, partial, sB2, gtab)
         if (g2p_dom && segmode) {
             dim3 grid((unsigned)((e->n_pad + 1023) / 1024), tab.nseg);
@@ -617,6 +639,8 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     // (a single list takes this flow too when the packed int8 GEMM 2 applies and the sample range alone fills the chip;
     // small cohorts keep the per-list flow, whose GEMM 2 can split K over workgroups)
     const bool segflow = !dom && (nbin > 1 || (g2p_ok && e->n_pad >= 192 * 1024));
+    e->last_flow = segflow ? 1 : 0;
+    e->last_g2 = 0;
     if (segflow) {
         std::vector<char> touched(nbin, 0);
         for (int b = 0; b < nbin; ++b)
@@ -802,6 +826,26 @@ extern "C" int pyrhe_engine_set_async(pyrhe_engine_t* e, int enable) {
     return PYRHE_OK;
 }
 
+extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t value) {
+    if (!e) return fail(PYRHE_EINVAL, "NULL engine");
+    switch (option) {
+        case PYRHE_OPT_G1_WORKGROUPS:
+            if (value < 1 || value > (1 << 20)) return fail(PYRHE_EINVAL, "G1_WORKGROUPS %lld outside 1..2^20", (long long)value);
+            e->opt_g1_wgs = (int)value; break;
+        case PYRHE_OPT_G2_PACKED: e->opt_g2_packed = value != 0; break;
+        case PYRHE_OPT_G2_IW:
+            if (value < 0 || value > 2) return fail(PYRHE_EINVAL, "G2_IW takes 0 (automatic), 1 or 2");
+            e->opt_g2_iw = (int)value; break;
+        case PYRHE_OPT_G2_SPLITS:
+            if (value < 0 || value > 4096) return fail(PYRHE_EINVAL, "G2_SPLITS %lld outside 0..4096", (long long)value);
+            e->opt_g2_splits = (int)value; break;
+        case PYRHE_OPT_DOTS_GENERIC: e->opt_dots_generic = value != 0; break;
+        case PYRHE_OPT_G1_SPLIT_MAJOR: e->opt_g1_split_major = value != 0; break;
+        default: return fail(PYRHE_EINVAL, "unknown option %d", option);
+    }
+    return PYRHE_OK;
+}
+
 extern "C" int pyrhe_engine_set_pipeline(pyrhe_engine_t* e, int enable) {
     if (!e) return fail(PYRHE_EINVAL, "NULL engine");
     e->pipeline = enable != 0;
@@ -822,9 +866,10 @@ extern "C" int pyrhe_engine_join(pyrhe_engine_t* e, void* stream_) {
 
 extern "C" int pyrhe_engine_block_stats(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                                         int32_t* out_sum, int32_t* out_nmiss, void* stream_) {
-    if (!e || !packed || !out_sum || !out_nmiss) return fail(PYRHE_EINVAL, "NULL argument");
+    if (!e) return fail(PYRHE_EINVAL, "NULL engine");
+    if (n_rows <= 0) return PYRHE_OK;            // a rank without local blocks: nothing to do, whatever the pointers are
+    if (!packed || !out_sum || !out_nmiss) return fail(PYRHE_EINVAL, "NULL argument");
     if (!e->rhs_set) return fail(PYRHE_ESTATE, "pyrhe_engine_set_rhs has not been called (keep mask unknown)");
-    if (n_rows <= 0) return PYRHE_OK;
     HIPCHK(hipSetDevice(e->device));
     if (e->vc) block_stats_kernel<true><<<(unsigned)((n_rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(packed, e->pitch, n_rows, e->keepmask, out_sum, out_nmiss);
     else block_stats_kernel<false><<<(unsigned)((n_rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(packed, e->pitch, n_rows, e->keepmask, out_sum, out_nmiss);
@@ -888,7 +933,7 @@ extern "C" int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, in
     bool fixed = period % 32 == 0 && n_batch == 1;
     for (int a = 0; a < nx && fixed; ++a) fixed = x[a].tot && !x[a].blk;
     for (int b = 0; b < ny && fixed; ++b) fixed = y[b].tot && !y[b].blk;
-    static const bool no_fast = getenv("PYRHE_DOTS_GENERIC") && atoi(getenv("PYRHE_DOTS_GENERIC")) != 0;
+    const bool no_fast = e->opt_dots_generic != 0;
     // ---- block rows against themselves (x and y are the same block-only rows): the self-Gram path
     bool self = period % 32 == 0 && nx == ny && nx <= 16;
     for (int a = 0; a < nx && self; ++a)
@@ -1051,11 +1096,41 @@ extern "C" int pyrhe_engine_loo_dots_multi(pyrhe_engine_t* e, const pyrhe_row_t*
     return PYRHE_OK;
 }
 
+extern "C" int pyrhe_engine_apply_projector(pyrhe_engine_t* e, const double* x, int64_t n_rows, int64_t n, const float* Wt,
+                                            const float* Q, int c, double* out, void* stream_) {
+    if (!e) return fail(PYRHE_EINVAL, "NULL engine");
+    if (n_rows <= 0) return PYRHE_OK;
+    if (!x || !Wt || !Q || !out) return fail(PYRHE_EINVAL, "NULL argument");
+    if (c < 1 || c > kProjMaxCov) return fail(PYRHE_EINVAL, "%d covariates outside 1..%d", c, kProjMaxCov);
+    if (n <= 0 || n_rows > 65535) return fail(PYRHE_EINVAL, "n must be positive and n_rows <= 65535");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipSetDevice(e->device));
+    const int n_chunks = (int)((n + kProjChunk - 1) / kProjChunk);
+    const size_t need = ((size_t)n_rows * n_chunks * c) * sizeof(double) + (size_t)n_rows * c * sizeof(float);
+    if (e->dots_partial_bytes < need) {
+        if (e->dots_partial) {
+            HIPCHK(hipDeviceSynchronize());       // earlier launches may still read the old scratch
+            HIPCHK(hipFree(e->dots_partial));
+            e->dots_partial = nullptr;
+            e->dots_partial_bytes = 0;
+        }
+        HIPCHK(hipMalloc(&e->dots_partial, need));
+        e->dots_partial_bytes = need;
+    }
+    double* partial = e->dots_partial;
+    float* u = reinterpret_cast<float*>(partial + (size_t)n_rows * n_chunks * c);
+    proj_dots_kernel<<<dim3(n_chunks, (unsigned)n_rows), 256, 0, stream>>>(x, n, Wt, c, n_chunks, partial);
+    proj_coef_kernel<<<(unsigned)n_rows, kProjMaxCov, 0, stream>>>(partial, n_chunks, Q, c, u);
+    proj_expand_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)n_rows), 256, 0, stream>>>(u, Wt, c, n, out);
+    HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
 extern "C" int pyrhe_recode_rows(uint8_t* packed, int64_t n_rows, int64_t pitch, int to_coding, void* stream_) {
-    if (!packed) return fail(PYRHE_EINVAL, "NULL argument");
     if (pitch <= 0 || pitch % 4) return fail(PYRHE_EINVAL, "pitch must be a positive multiple of 4");
     if (to_coding != PYRHE_CODING_PLINK && to_coding != PYRHE_CODING_VALUE) return fail(PYRHE_EINVAL, "unknown coding %d", to_coding);
-    if (n_rows <= 0) return PYRHE_OK;
+    if (n_rows <= 0) return PYRHE_OK;            // an empty buffer (a rank without local blocks) has no address
+    if (!packed) return fail(PYRHE_EINVAL, "NULL argument");
     recode_rows_kernel<<<8192, 256, 0, (hipStream_t)stream_>>>(reinterpret_cast<uint32_t*>(packed), n_rows * (pitch / 4), to_coding == PYRHE_CODING_VALUE);
     HIPCHK(hipGetLastError());
     return PYRHE_OK;
@@ -1094,6 +1169,7 @@ extern "C" int pyrhe_engine_profile(pyrhe_engine_t* e, int enable) {
     if (!e) return fail(PYRHE_EINVAL, "NULL engine");
     e->evs.clear();
     e->pool_used = 0;
+    e->prof_failed = false;
     e->profile = enable != 0;
     return PYRHE_OK;
 }
@@ -1101,6 +1177,7 @@ extern "C" int pyrhe_engine_profile(pyrhe_engine_t* e, int enable) {
 extern "C" int pyrhe_engine_profile_read(pyrhe_engine_t* e, double* ms_gemm1, double* ms_mid, double* ms_gemm2,
                                          int64_t* launches) {
     if (!e) return fail(PYRHE_EINVAL, "NULL engine");
+    if (e->prof_failed) return fail(PYRHE_ENOMEM, "hipEventCreate failed while profiling: the timings of this pass are incomplete");
     double t[3] = {0, 0, 0};
     int64_t n = 0;
     for (auto& ev : e->evs) {

@@ -40,6 +40,7 @@ SYMBOLS = {
     "pyrhe_engine_set_async": (_i32, [_vp, _i32]),
     "pyrhe_engine_join": (_i32, [_vp, _vp]),
     "pyrhe_engine_set_pipeline": (_i32, [_vp, _i32]),
+    "pyrhe_engine_set_option": (_i32, [_vp, _i32, _i64]),
     "pyrhe_decode_rows": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "pyrhe_recode_rows": (_i32, [_vp, _i64, _i64, _i32, _vp]),
     "pyrhe_engine_set_coding": (_i32, [_vp, _i32]),
@@ -47,6 +48,7 @@ SYMBOLS = {
     "pyrhe_sum_blocks_weighted": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     "pyrhe_engine_loo_dots": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "pyrhe_engine_loo_dots_multi": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pyrhe_engine_apply_projector": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp]),
     "pyrhe_synth_genotypes": (_i32, [_vp, _i64, _i64, _i64, _u64, _i64, _vp]),
     "pyrhe_engine_info": (_i64, [_vp, _i32]),
     "pyrhe_engine_profile": (_i32, [_vp, _i32]),
@@ -152,6 +154,8 @@ def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28) -
 
 
 CODINGS = {"plink": 0, "value": 1}
+# PYRHE_OPT_* of include/pyrhe_sketch.h: launch-shape knobs, every value computes the same results
+OPTIONS = {"g1_workgroups": 1, "g2_packed": 2, "g2_iw": 3, "g2_splits": 4, "dots_generic": 5, "g1_split_major": 6}
 
 
 def recode_rows(packed: torch.Tensor, to: str = "value") -> torch.Tensor:
@@ -335,6 +339,17 @@ class SketchEngine:
         _check(self.lib.pyrhe_engine_set_coding(self._h, CODINGS[coding]), "pyrhe_engine_set_coding")
         self.coding = coding
 
+    def set_option(self, name: str, value: int):
+        """Launch-shape knob of ``pyrhe_engine_set_option`` (see ``OPTIONS``)."""
+        _check(self.lib.pyrhe_engine_set_option(self._h, OPTIONS[name], int(value)), f"pyrhe_engine_set_option({name})")
+
+    def last_path(self) -> dict:
+        """Which kernels the last sketch call launched (``pyrhe_engine_info`` 6..8): ``gemm1`` = 100 + tiles for the int8
+        kernel / tiles for the fp16 kernel, ``gemm2`` = 11 / 12 packed int8 kernel with one / two column groups, 1 fp16
+        kernel, 0 none; ``segmented`` = one GEMM 1 over all lists of the call."""
+        g1, g2, fl = (int(self.lib.pyrhe_engine_info(self._h, w)) for w in (6, 7, 8))
+        return {"gemm1": g1, "gemm2": g2, "segmented": bool(fl)}
+
     def set_async(self, enable: bool):
         """Defer the per-call join: consecutive blocks then overlap (GEMM 1 of block j+1 beside GEMM 2 of block j)."""
         _check(self.lib.pyrhe_engine_set_async(self._h, 1 if enable else 0), "pyrhe_engine_set_async")
@@ -372,6 +387,19 @@ class SketchEngine:
             _check(self.lib.pyrhe_engine_loo_dots(self._h, C.cast(xa, _vp), len(x), C.cast(ya, _vp), len(y), int(period),
                                                   int(n_sub), int(n_batch), _ptr(out), _stream_ptr(self.device)),
                    "pyrhe_engine_loo_dots")
+        return out
+
+    def apply_projector(self, x: torch.Tensor, Wt32: torch.Tensor, Q32: torch.Tensor) -> torch.Tensor:
+        """``W (Q (W^T x))`` for every row of ``x [..., n]`` float64 (``pyrhe_engine_apply_projector``: the reference's
+        float32 ``_compute_UXXz``, base.py:407-408).  ``Wt32 [c, n]`` / ``Q32 [c, c]`` float32 on the device; float64 out."""
+        assert x.dtype == torch.float64 and x.is_contiguous() and Wt32.dtype == torch.float32 and Wt32.is_contiguous()
+        assert Q32.dtype == torch.float32 and Q32.is_contiguous() and Wt32.shape[1] == x.shape[-1]
+        out = torch.empty_like(x)
+        n = x.shape[-1]
+        n_rows = x.numel() // n if n else 0
+        with torch.cuda.device(self.device):
+            _check(self.lib.pyrhe_engine_apply_projector(self._h, _ptr(x), n_rows, n, _ptr(Wt32), _ptr(Q32), Wt32.shape[0],
+                                                         _ptr(out), _stream_ptr(self.device)), "pyrhe_engine_apply_projector")
         return out
 
     @staticmethod

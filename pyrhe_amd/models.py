@@ -60,23 +60,34 @@ class Base:
         torch.cuda.set_device(self.device)
         self.log._debug(f"Using device {self.device}")
 
-        # seed -> private legacy stream replaying the reference's global one (base.py:72-73)
+        # seed -> private legacy stream replaying the reference's global one (base.py:72-73).  Every rank must draw the
+        # SAME probe vectors, generated annotation and imputation stream: an unset seed is chosen on rank 0 and broadcast.
         self.seed = int(time.process_time()) if seed is None else int(seed)
+        if self.world > 1:
+            box = [self.seed]
+            dist.broadcast_object_list(box, src=0)
+            if seed is not None and int(box[0]) != self.seed:
+                raise ValueError(f"rank {self.rank} was given seed {self.seed}, rank 0 seed {box[0]}: all ranks need the same seed")
+            self.seed = int(box[0])
         rs = np.random.RandomState(self.seed)
 
         self.num_indv_original, fam_df = rio.read_fam(geno_file + ".fam")
         self.num_snp = rio.count_bim(geno_file + ".bim")
-        self._rng_prefix = 0
+        self._rng_prefix, self._rng_high = 0, 2
         if annot_file is None:
             if num_bin is None:
                 raise ValueError("Must specify number of bins if annot file is not provided")
             annot_file = "generated_annot"
-            with open(annot_file, "w") as f:                      # file_processing.py:102-111, same draws
-                for _ in range(self.num_snp):
-                    row = [0] * num_bin
-                    row[rs.randint(0, num_bin)] = 1
-                    f.write(" ".join(str(v) for v in row) + "\n")
-            self._rng_prefix = self.num_snp
+            draws = rs.randint(0, num_bin, self.num_snp)          # file_processing.py:102-111: one randint per SNP, same stream
+            if self.rank == 0:                                    # one writer; the other ranks read it after the barrier
+                with open(annot_file, "w") as f:
+                    for d_ in draws:
+                        row = [0] * num_bin
+                        row[int(d_)] = 1
+                        f.write(" ".join(str(v) for v in row) + "\n")
+            if self.world > 1:
+                dist.barrier()
+            self._rng_prefix, self._rng_high = self.num_snp, int(num_bin)
         self.num_bin, self.annot_matrix, self.len_bin = rio.read_annot(annot_file)
 
         self.pheno_file = pheno_file
@@ -150,7 +161,7 @@ class Base:
                             missing_indv=self.missing_indv, Z=self.all_zb, cov=self.cov_matrix, env=self.env,
                             genie_model=self.genie_model, impute=self.geno_impute_methods, seed=self.seed,
                             streaming=self.streaming, compat=self.compat, recompute_pass2=self.recompute_pass2,
-                            rng_prefix_draws=self._rng_prefix)
+                            rng_prefix_draws=self._rng_prefix, rng_prefix_high=self._rng_high)
 
     def pre_compute(self):
         t0 = time.time()
@@ -303,7 +314,7 @@ class RHE_DOM(Base):
         return SketchRunner(self._engines, self.geno_dev, self.plan, self.local_blocks, n_orig=self.num_indv_original,
                             missing_indv=self.missing_indv, Z=self.all_zb, cov=self.cov_matrix, impute=self.geno_impute_methods,
                             seed=self.seed, streaming=self.streaming, compat=self.compat, recompute_pass2=self.recompute_pass2,
-                            rng_prefix_draws=self._rng_prefix, dom=True)
+                            rng_prefix_draws=self._rng_prefix, rng_prefix_high=self._rng_high, dom=True)
 
     def run(self, method):
         log = self.log._log
@@ -379,7 +390,7 @@ class GENIE(Base):
                             missing_indv=self.missing_indv, Z=self.all_zb, cov=self.cov_matrix, env=self.env,
                             genie_model=self.genie_model, impute=self.geno_impute_methods, seed=self.seed,
                             streaming=self.streaming, compat=self.compat, recompute_pass2=self.recompute_pass2,
-                            rng_prefix_draws=self._rng_prefix)
+                            rng_prefix_draws=self._rng_prefix, rng_prefix_high=self._rng_high)
 
     def estimate(self, method: str = "lstsq"):
         """Variance components and their trace-adjusted copies sigma_i * T[i, ne] (genie.py:97-144)."""

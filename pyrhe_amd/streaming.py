@@ -13,7 +13,8 @@ MI355X-first differences (results identical within the stated tolerance):
   * blocks are sharded over ranks (one process per GPU) by the reference's own contiguous rule and the
     per-bin accumulators are summed with ONE all-reduce (RCCL over xGMI); leave-one-out systems are built
     where the block lives and only ``(ne+1)^2 + ne + 1`` numbers per block are gathered;
-  * the Gram matrices of the normal equations are float64 GEMMs on the GPU (torch, plumbing).
+  * the Gram matrices of the normal equations and the covariate projector U = W Q W^T come from the engine
+    (``pyrhe_engine_loo_dots*``, ``pyrhe_engine_apply_projector``); torch holds memory and does [blocks, ne, ne] algebra.
 """
 from __future__ import annotations
 
@@ -153,7 +154,8 @@ class SketchRunner:
                  n_orig: int, missing_indv: Sequence[int], Z: np.ndarray, cov: Optional[np.ndarray] = None,
                  env: Optional[np.ndarray] = None, genie_model: Optional[str] = None,
                  impute: str = "binary", seed: int = 0, streaming: bool = True, compat: str = "reference",
-                 recompute_pass2: bool = False, rng_prefix_draws: int = 0, group=None, dom: bool = False):
+                 recompute_pass2: bool = False, rng_prefix_draws: int = 0, group=None, dom: bool = False,
+                 solo: bool = False, rng_prefix_high: int = 2):
         self.engs = list(engines) if isinstance(engines, (list, tuple)) else [engines]
         self.eng = self.engs[0]
         self.geno = geno
@@ -178,8 +180,10 @@ class SketchRunner:
         self.compat = compat
         self.recompute_pass2 = bool(recompute_pass2)
         self.rng_prefix_draws = int(rng_prefix_draws)
+        self.rng_prefix_high = int(rng_prefix_high)     # generate_annot drew randint(0, num_bin) per SNP (rejection sampling: the bound matters)
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # solo: a runner over data every rank holds by itself (a cross-check beside a sharded job): no collectives
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized() and not solo) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.device = geno.device
         self.n_pad = self.eng.n_pad
@@ -209,11 +213,14 @@ class SketchRunner:
             self.Q32 = self.Q64.to(torch.float32)
             self.UZ64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.UZ.T)))  # [k, n_pad]
             self.WT64 = self.W64.T.contiguous()                                              # [c, n_pad]
+            self.WT32 = self.WT64.to(torch.float32)
         self.Z64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.Z.T)))        # [k, n_pad] f64
         if self.env is not None:
             self.env_pad = self._pad_cols(torch.from_numpy(self.env[None, :]))[0]            # [n_pad] f64
             self.env32 = self.env_pad.to(torch.float32)
         self.pass2_impl = "hip"       # "torch": materialised cross-check path (tests)
+        self.one_slot = False         # this trait group keeps ONE block slot and re-sketches in pass 2 (begin_trait decides)
+        self.row_limit = None         # rows one engine call may address; None = from the engine's 32-bit byte offsets
         self._entries_cache = {}
         self._stats = None
         self._check_missing = True
@@ -325,7 +332,7 @@ class SketchRunner:
             return lambda j, m: np.random.RandomState(self.seed).random_sample(m)
         rs = np.random.RandomState(self.seed)
         if self.rng_prefix_draws:
-            rs.randint(0, 2, self.rng_prefix_draws)
+            rs.randint(0, self.rng_prefix_high, self.rng_prefix_draws)
         rs.randn(self.N, self.k)
         skip = 0
         for p in range(pass_index + 1):
@@ -352,11 +359,51 @@ class SketchRunner:
         if self.dom:
             return 1
         cap = int(getattr(self.eng, "sub_snps", 0)) or self.plan.max_block
-        pitch = int(getattr(self.eng, "pitch", self.n_pad // 4))
         by_entries = cap // max(self.plan.max_block, 1)
-        by_bytes = ((1 << 32) - 1) // max(self.plan.max_block * pitch, 1)
+        by_bytes = self._row_limit() // max(self.plan.max_block, 1)
         by_lists = MAX_SEGMENTS // max(self.plan.n_bin, 1)
         return max(1, min(by_entries, by_bytes, by_lists))
+
+    def _row_limit(self) -> int:
+        """Rows one engine call can address: its row byte offsets are 32-bit (rows * pitch < 2^32, rows < 2^24)."""
+        if self.row_limit is not None:
+            return int(self.row_limit)
+        pitch = int(getattr(self.eng, "pitch", self.n_pad // 4))
+        return max(1, min(((1 << 32) - 1) // max(pitch, 1), (1 << 24) - 1))
+
+    def _pieces(self, j: int):
+        """A block with more rows than one engine call addresses (N = 500k: over 34 308 SNPs, e.g. M = 1M with jn < 30) as
+        consecutive row sub-ranges ``(a, b, entries, offsets)`` with the bin lists rebased to each piece; the later pieces
+        ACCUMULATE into the block's outputs.  Exact in the reference's sense: standardisation is per SNP, so the block
+        sketch is the sum over its SNPs in any grouping (float32 additions in list order either way).  None: one call."""
+        s, e = self.plan.range(j)
+        lim = self._row_limit()
+        if e - s <= lim:
+            return None
+        key = ("pieces", j, lim)
+        if key not in self._entries_cache:
+            cat, offs = self.plan.entries(j)
+            out = []
+            for a in range(0, e - s, lim):
+                b = min(a + lim, e - s)
+                lists = []
+                for bn in range(self.plan.n_bin):
+                    l = cat[offs[bn]:offs[bn + 1]]
+                    lists.append((l[(l >= a) & (l < b)] - a).astype(np.int32))
+                po = np.zeros(self.plan.n_bin + 1, np.int64)
+                po[1:] = np.cumsum([len(x) for x in lists])
+                ent = np.concatenate(lists) if po[-1] else np.zeros(0, np.int32)
+                out.append((a, b, torch.from_numpy(ent).to(self.device), po))
+            self._entries_cache[key] = out
+        return self._entries_cache[key]
+
+    def _sketch_call(self, p: int, rows, ent, offs, fill, osk, onm, oskd=None, onmd=None, accumulate=False):
+        """One engine call of pass ``p`` (additive, or additive + dominance for RHE_DOM) into the given outputs."""
+        if self.dom:
+            self.engs[p].sketch_block_dom(rows, ent, offs, fill=fill, out_sketch=osk, out_norm=onm, out_sketch_dom=oskd,
+                                          out_norm_dom=onmd, accumulate=accumulate)
+        else:
+            self.engs[p].sketch_block(rows, ent, offs, fill=fill, out_sketch=osk, out_norm=onm, accumulate=accumulate)
 
     def _batch_entries(self, js):
         """Entry lists of the blocks ``js`` (consecutive) as ONE call: row indices relative to the first row of the batch,
@@ -424,17 +471,22 @@ class SketchRunner:
                         fill = torch.cat([f if f is not None else torch.zeros(m_, dtype=torch.float32, device=self.device)
                                           for f, m_ in parts]) if len(parts) > 1 else parts[0][0]
                         fills.append(fill)
+                pieces = self._pieces(js[0]) if len(js) == 1 else None
                 for p in range(self.n_pass):
-                    if self.dom:
-                        self.engs[p].sketch_block_dom(rows, ent, offs, fill=fill, out_sketch=out_sk[p][jl],
-                                                      out_norm=out_norm[p][jl], out_sketch_dom=self.blocks_skd[p][jl],
-                                                      out_norm_dom=self.blocks_nmd[p][jl], accumulate=False)
+                    if pieces is not None:          # a block beyond the 32-bit row offsets of one call: row sub-ranges
+                        for i_, (a, b, ent_p, offs_p) in enumerate(pieces):
+                            self._sketch_call(p, rows[a:b], ent_p, offs_p, None if fill is None else fill[a:b].contiguous(),
+                                              out_sk[p][jl], out_norm[p][jl], self.blocks_skd[p][jl] if self.dom else None,
+                                              self.blocks_nmd[p][jl] if self.dom else None, accumulate=i_ > 0)
+                    elif self.dom:
+                        self._sketch_call(p, rows, ent, offs, fill, out_sk[p][jl], out_norm[p][jl], self.blocks_skd[p][jl],
+                                          self.blocks_nmd[p][jl])
                     else:
                         n = len(js)
                         osk = out_sk[p][jl:jl + n]
                         onm = out_norm[p][jl:jl + n]
-                        self.engs[p].sketch_block(rows, ent, offs, fill=fill, out_sketch=osk.reshape(n * nb, *osk.shape[2:]),
-                                                  out_norm=onm.reshape(n * nb, onm.shape[2]), accumulate=False)
+                        self._sketch_call(p, rows, ent, offs, fill, osk.reshape(n * nb, *osk.shape[2:]),
+                                          onm.reshape(n * nb, onm.shape[2]))
                 if one_slot:
                     after_block(jl0, js[0])
         finally:
@@ -445,6 +497,9 @@ class SketchRunner:
     def _apply_U(self, v: torch.Tensor, f32: bool) -> torch.Tensor:
         """``W (Q (W^T v))`` for rows of v ``[..., n_pad]``; float32 like _compute_UXXz (base.py:407-408) or float64
         like setup_lhs_rhs_jackknife (base.py:584-586).  Result float64."""
+        proj = getattr(self.eng, "apply_projector", None)
+        if f32 and proj is not None:          # the HIP kernels (pyrhe_engine_apply_projector); stand-in engines of the CPU tests lack them
+            return proj(v.to(torch.float64).contiguous(), self.WT32, self.Q32)
         W, Q = (self.W32, self.Q32) if f32 else (self.W64, self.Q64)
         x = v.to(W.dtype)
         shp = x.shape
@@ -475,17 +530,33 @@ class SketchRunner:
         self._install_rhs(y)
         dev = self.device
         # The per-block sketches stay in HBM for pass 2 when they fit (C3: 2 GB, C4: 32 GB of the 288); otherwise pass 2
-        # re-sketches every block like the reference's second pass and only one block's outputs are ever resident.
-        store_bytes = jl * nb * sum(ns for ns, _ in self.pass_shapes) * self.n_pad * 4 * (2 if self.dom else 1)
-        if not self.recompute_pass2 and dev.type == "cuda":
+        # re-sketches every block like the reference's second pass and only one block's outputs are ever resident.  The
+        # decision is per trait group: a store of the right shape left by the previous group is reused as it is, any other
+        # one is released (and torch's cached blocks returned) BEFORE the free memory is read.
+        shapes = [(ns, nn) for ns, nn in self.pass_shapes]
+        full = [(jl, nb, ns, self.n_pad) for ns, _ in shapes]
+        old = getattr(self, "blocks_sk", None)
+        if old is not None and not self.one_slot and [tuple(b.shape) for b in old] == full and \
+                [b.shape[2] for b in self.blocks_nm] == [nn for _, nn in shapes]:
+            for b in self.blocks_nm:
+                b.zero_()
+            if self.dom:
+                for b in self.blocks_nmd:
+                    b.zero_()
+            return
+        self.blocks_sk = self.blocks_nm = self.blocks_skd = self.blocks_nmd = None
+        self.one_slot = bool(self.recompute_pass2)
+        store_bytes = jl * nb * sum(ns for ns, _ in shapes) * self.n_pad * 4 * (2 if self.dom else 1)
+        if not self.one_slot and dev.type == "cuda":
+            torch.cuda.empty_cache()
             free = torch.cuda.mem_get_info(dev)[0]
             if store_bytes > 0.8 * free:
-                self.recompute_pass2 = True
+                self.one_slot = True
                 self.timings["recompute_pass2"] = f"auto: {store_bytes / 1e9:.1f} GB of block sketches vs {free / 1e9:.1f} GB free"
-        if self.recompute_pass2:
+        if self.one_slot:
             jl = min(jl, 1)
-        self.blocks_sk = [torch.empty((jl, nb, ns, self.n_pad), dtype=torch.float32, device=dev) for ns, _ in self.pass_shapes]
-        self.blocks_nm = [torch.zeros((max(jl, 1), nb, nn), dtype=torch.float64, device=dev) for _, nn in self.pass_shapes]
+        self.blocks_sk = [torch.empty((jl, nb, ns, self.n_pad), dtype=torch.float32, device=dev) for ns, _ in shapes]
+        self.blocks_nm = [torch.zeros((max(jl, 1), nb, nn), dtype=torch.float64, device=dev) for _, nn in shapes]
         self.blocks_skd = [torch.empty_like(b) for b in self.blocks_sk] if self.dom else None
         self.blocks_nmd = [torch.zeros_like(b) for b in self.blocks_nm] if self.dom else None
 
@@ -537,39 +608,59 @@ class SketchRunner:
 
     def pass1(self):
         """One streaming sketch pass over the local blocks (base_streaming.py:85-104) + aggregate
-        (base_streaming.py:21-58 / base.py:465-500: float64 sums in block order) + the cross-GPU all-reduce."""
+        (base_streaming.py:21-58 / base.py:465-500: float64 sums in block order) + the cross-GPU all-reduce.
+
+        Multi-GPU (world > 1): the float64 totals are all-reduced IN PLACE, in the engines' own layout
+        ``[bin][sketch column][n_pad]`` (every estimate-level quantity below is linear in them), one asynchronous
+        collective per bucket = (engine pass, array), issued as soon as that bucket's block sum is enqueued so that it
+        overlaps the block sums of the next bucket; the small norm sums travel in one packed buffer.  Float64 on the wire:
+        the single-GPU path adds the blocks in float64 (base.py:468-471 widens every float32 block result before adding),
+        and a float32 hand-over would round every rank's partial sum to 6e-8 -- the 1 / 2 / 4 / 8-GPU results would then
+        agree to 1e-7 instead of 1e-15.  Bytes per rank and pass (ring: x 2 (G-1)/G on the links): k = 10, N = 500k:
+        1 bin 40 MB; 8 bins + covariates 640 MB (+ 320 MB for the (jn - j)-weighted XXz of quirk Q4); G + GxE 80 MB."""
         plan, k = self.plan, self.k
         jn, jl, dev = plan.n_jack, self.j1 - self.j0, self.device
-        ne_g = 2 * plan.n_bin if self.dom else plan.n_bin + self.n_gxe
         f64 = torch.float64
         use_cov = self.cov is not None
         q4 = use_cov and self.streaming and self.compat == "reference"
-        wsum = None
         w = torch.arange(jn - self.j0, jn - self.j0 - jl, -1, dtype=f64, device=dev) if jl else torch.zeros(0, dtype=f64, device=dev)
-        w_sk = w_skd = None
-        if not self.recompute_pass2:
+        handles = []
+
+        def reduce_async(t):
+            if self.world > 1:
+                h = self._allreduce(t, async_op=True)
+                if h is not None:
+                    handles.append(h)
+            return t
+
+        def z_part(lst):
+            """The XXz columns (group Z) of weighted totals as contiguous tensors: all that quirk Q4 needs of them."""
+            return {p_: lst[p_][:, c0:c0 + nc].contiguous() for p_, c0, _, nc in self.loc["Z"]}
+
+        tot_skd = tot_nmd = w_sk = w_skd = None
+        if not self.one_slot:
             self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0)
-            # Block sums as ONE float64 reduction over the stored per-block sketches (the reference adds the blocks one
-            # by one in float64, base.py:468-471; any order agrees to 1e-16).  U is linear, so the "fixed" UXXz total is
-            # U applied to the total (float32 rounding order differs from per-block application at the 1e-7 level).
-            tot_sk = [self.eng.sum_blocks(b) for b in self.blocks_sk]
+            # Block sums as ONE float64 reduction over the stored per-block sketches per bucket (the reference adds the
+            # blocks one by one in float64, base.py:468-471; any order agrees to 1e-16).  U is linear, so the "fixed" UXXz
+            # total is U applied to the total (float32 rounding order differs from per-block application at 1e-7).
+            tot_sk = [reduce_async(self.eng.sum_blocks(b)) for b in self.blocks_sk]
             tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
-            tot_skd = tot_nmd = None
             if self.dom:
-                tot_skd = [self.eng.sum_blocks(b) for b in self.blocks_skd]
+                tot_skd = [reduce_async(self.eng.sum_blocks(b)) for b in self.blocks_skd]
                 tot_nmd = [b[:jl].sum(dim=0) for b in self.blocks_nmd]
             if q4:
-                w_sk = [self.eng.sum_blocks(b, w) for b in self.blocks_sk]
-                w_skd = [self.eng.sum_blocks(b, w) for b in self.blocks_skd] if self.dom else None
+                w_sk = z_part([self.eng.sum_blocks(b, w) for b in self.blocks_sk])
+                w_skd = z_part([self.eng.sum_blocks(b, w) for b in self.blocks_skd]) if self.dom else None
         else:
             # one-slot store: every block is added to the float64 totals (and the (jn - j)-weighted ones of quirk Q4)
             # right after its sketch, in block order
             zeros = lambda lst: [torch.zeros(b.shape[1:], dtype=f64, device=dev) for b in lst]
             tot_sk, tot_nm = zeros(self.blocks_sk), zeros(self.blocks_nm)
             tot_skd, tot_nmd = (zeros(self.blocks_skd), zeros(self.blocks_nmd)) if self.dom else (None, None)
+            wf = wfd = None
             if q4:
-                w_sk = zeros(self.blocks_sk)
-                w_skd = zeros(self.blocks_skd) if self.dom else None
+                wf = zeros(self.blocks_sk)
+                wfd = zeros(self.blocks_skd) if self.dom else None
 
             def add(jl_i, j):
                 for p_ in range(self.n_pass):
@@ -579,31 +670,41 @@ class SketchRunner:
                         tot_skd[p_] += self.blocks_skd[p_][0]
                         tot_nmd[p_] += self.blocks_nmd[p_][0]
                     if q4:
-                        w_sk[p_].add_(self.blocks_sk[p_][0], alpha=float(jn - j))
+                        wf[p_].add_(self.blocks_sk[p_][0], alpha=float(jn - j))
                         if self.dom:
-                            w_skd[p_].add_(self.blocks_skd[p_][0], alpha=float(jn - j))
+                            wfd[p_].add_(self.blocks_skd[p_][0], alpha=float(jn - j))
             self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0, after_block=add)
+            for t in tot_sk + (tot_skd or []):
+                reduce_async(t)
+            if q4:
+                w_sk, w_skd = z_part(wf), (z_part(wfd) if self.dom else None)
+        if self.world > 1:
+            for d_ in (w_sk, w_skd):
+                for t in (d_ or {}).values():
+                    reduce_async(t)
+            small = tot_nm + (tot_nmd or [])                       # [nbin, n_norm] each: one packed buffer
+            flat = torch.cat([t.reshape(-1) for t in small])
+            self._allreduce(flat)
+            off = 0
+            for t in small:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+            for h in handles:
+                h.wait()
         tot_A, tot_C, tot_r = self._block_estimates(tot_sk, tot_nm, tot_skd, tot_nmd)
         tot_A, tot_r = tot_A.contiguous(), tot_r.clone()
         tot_C = tot_C.contiguous() if use_cov else None
+        wsum = None
         if q4:
             # quirk Q4 (streaming_rhe.py:18-21): the reference applies U to the RUNNING sum of XXz after every block;
             # U is linear, so sum_j U(sum_{i<=j} XXz_i) = U(sum_i (jn - i) XXz_i): one weighted block sum, one U
             # (float32 rounding order differs from the block-by-block application at the 1e-7 level)
-            wsum = self._block_estimates(w_sk, tot_nm, w_skd, tot_nmd)[0].contiguous()
-        D_tot = (self._apply_U(wsum if q4 else tot_A, f32=True) if use_cov else None)
-        if self.world > 1:
-            # ONE all-reduce per pass: XXz | yXXy (| XXUz | the (jn - j)-weighted XXz of quirk Q4) packed in one buffer
-            parts = [tot_A, tot_r] + ([tot_C] if use_cov else []) + ([wsum] if q4 else [])
-            flat = torch.cat([t.reshape(-1) for t in parts])
-            self._allreduce(flat)
-            off = 0
-            for t in parts:
-                t.copy_(flat[off:off + t.numel()].view_as(t))
-                off += t.numel()
-            del flat
-            if use_cov:   # U is linear: sum_j U(running_j) = U(sum_j (jn - j) XXz_j)  (float32 rounding order differs)
-                D_tot = self._apply_U(wsum if q4 else tot_A, f32=True)
+            cat = lambda d_: torch.cat([d_[p_] for p_, _, _, _ in self.loc["Z"]], dim=1) if len(self.loc["Z"]) > 1 else d_[self.loc["Z"][0][0]]
+            wsum = cat(w_sk)
+            if self.dom:
+                wsum = torch.cat([wsum, cat(w_skd)], dim=0)
+            wsum = wsum.contiguous()
+        D_tot = self._apply_U(wsum if q4 else tot_A, f32=True) if use_cov else None     # a10: pyrhe_engine_apply_projector
         self.tot_A, self.tot_C, self.tot_r, self.D_tot = tot_A, tot_C, tot_r, D_tot
         self.tot_sk = tot_A            # [n_est_g, k, n_pad] float64 (kept under the old name for callers)
 
@@ -673,7 +774,7 @@ class SketchRunner:
         js = list(range(self.j0, self.j1))
         if jn == 1 and js == [0]:                               # base.py:654-655: the only slot is the whole-data one
             js = []
-        if js and not self.recompute_pass2:
+        if js and not self.one_slot:
             store = (self.blocks_sk, self.blocks_nm, self.blocks_skd, self.blocks_nmd)
             Ts, qs = self._loo_systems(tots, nxe, store, len(js), M[js], yy)
             local = [(j, Ts[i], qs[i]) for i, j in enumerate(js)]
@@ -689,9 +790,7 @@ class SketchRunner:
         if jn == 1 and self.j0 == 0 and self.j1 == 1:
             local = [(0, T_tot, q_tot)]
         if self.world > 1:
-            gathered = [None] * self.world
-            dist.all_gather_object(gathered, local, group=self.group)
-            local = [item for part in gathered for item in part]
+            local = self._gather_systems(local, T_tot.shape, q_tot.shape)
         local.sort(key=lambda t: t[0])
         Ts = np.stack([t[1] for t in local] + [T_tot])
         qs = np.stack([t[2] for t in local] + [q_tot])           # [jn+1, n_traits, ne+1]
@@ -704,7 +803,7 @@ class SketchRunner:
         jn, use_cov = self.plan.n_jack, self.cov is not None
         local = []
         for jl_i, j in enumerate(range(self.j0, self.j1)):
-            stored = self._resketch(j) if self.recompute_pass2 else self._stored_block(jl_i)
+            stored = self._resketch(j) if self.one_slot else self._stored_block(jl_i)
             slot = jn if (jn == 1 and j == 0) else j          # base.py:654-655
             if slot == jn:
                 T, q = self._system(*with_nxe(tot_A, tot_C, D_tot, tot_r), M[jn], yy)
@@ -719,9 +818,7 @@ class SketchRunner:
             local.append((j, T, q))
         T_tot, q_tot = self._system(*with_nxe(tot_A, tot_C, D_tot, tot_r), M[jn], yy)
         if self.world > 1:
-            gathered = [None] * self.world
-            dist.all_gather_object(gathered, local, group=self.group)
-            local = [item for part in gathered for item in part]
+            local = self._gather_systems(local, T_tot.shape, q_tot.shape)
         local.sort(key=lambda t: t[0])
         return Systems(np.stack([t[1] for t in local] + [T_tot]), np.stack([t[2] for t in local] + [q_tot]), M)
 
@@ -988,18 +1085,45 @@ class SketchRunner:
         """Sketch block j again (the reference's pass 2 re-reads and re-imputes, base_streaming.py:110-118).  Blocks are
         visited in ascending order; missing calls get the SAME fill values as in pass 1: the reference's pass-2 worker
         is forked from the same parent state as its pass-1 worker (mp_handler.py:28-37), so it replays the same draws."""
-        ent, offs = self._entries(j)
         fill = None
         if self._check_missing and self._ingest_stats()[1].any():
             fill = self._block_fills(0)[j - self.j0]
-        if self.dom:
-            outs = [self.engs[p].sketch_block_dom(self._block_rows(j), ent, offs, fill=fill) for p in range(self.n_pass)]
-            return [o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], [o[3] for o in outs]
-        outs = [self.engs[p].sketch_block(self._block_rows(j), ent, offs, fill=fill) for p in range(self.n_pass)]
-        return [o[0] for o in outs], [o[1] for o in outs], None, None
+        nb, dev = self.plan.n_bin, self.device
+        rows = self._block_rows(j)
+        pieces = self._pieces(j) or [(0, rows.shape[0]) + self._entries(j)]
+        sk = [torch.empty((nb, e_.n_sketch, self.n_pad), dtype=torch.float32, device=dev) for e_ in self.engs[:self.n_pass]]
+        nm = [torch.empty((nb, max(e_.n_norm, 1)), dtype=torch.float64, device=dev) for e_ in self.engs[:self.n_pass]]
+        skd = [torch.empty_like(t) for t in sk] if self.dom else None
+        nmd = [torch.empty_like(t) for t in nm] if self.dom else None
+        for p in range(self.n_pass):
+            for i_, (a, b, ent, offs) in enumerate(pieces):
+                self._sketch_call(p, rows[a:b], ent, offs, None if fill is None else fill[a:b].contiguous(), sk[p], nm[p],
+                                  skd[p] if self.dom else None, nmd[p] if self.dom else None, accumulate=i_ > 0)
+        return sk, nm, skd, nmd
 
-    def _allreduce(self, t: torch.Tensor):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+    def _allreduce(self, t: torch.Tensor, async_op: bool = False):
+        """Sum over the ranks, in place (RCCL over xGMI under the "nccl" backend); ``async_op``: returns the work handle."""
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def _gather_systems(self, local, t_shape, q_shape):
+        """Every rank's ``(j, T_j, q_j)`` to every rank as ONE tensor all-gather (the reference's result Queue,
+        base_streaming.py:141-172): rows ``[j | T_j | q_j]`` float64, padded with j = -1 to the largest shard."""
+        per = max(1, max(b - a for a, b in shard_ranges(self.plan.n_jack, self.world)))
+        nt_, nq = int(np.prod(t_shape)), int(np.prod(q_shape))
+        buf = np.full((per, 1 + nt_ + nq), -1.0)
+        for i, (j, T, q) in enumerate(local):
+            buf[i, 0] = j
+            buf[i, 1:1 + nt_] = np.asarray(T).reshape(-1)
+            buf[i, 1 + nt_:] = np.asarray(q).reshape(-1)
+        mine = torch.from_numpy(buf).to(self.device)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        out = []
+        for part in parts:
+            rows = part.cpu().numpy()
+            for r in rows[rows[:, 0] >= 0]:
+                out.append((int(r[0]), r[1:1 + nt_].reshape(t_shape).copy(), r[1 + nt_:].reshape(q_shape).copy()))
+        return out
 
     # ---- normal equations (base.py:568-628) ----------------------------------------------------
     def _system(self, A, C, D, r, M_row, yy: float):

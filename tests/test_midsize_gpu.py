@@ -217,7 +217,7 @@ def test_store_falls_back_to_one_slot_when_hbm_is_short(monkeypatch):
         if short:
             monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (1 << 20, 1 << 38))
         sysm = runner.run_trait(y, check_missing=False)
-        assert runner.recompute_pass2 == short
+        assert runner.one_slot == short
         assert runner.blocks_sk[0].shape[0] == (1 if short else jn)
         out.append(sysm)
         eng.close()
