@@ -121,11 +121,22 @@ def _t32(x: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(x).float()
 
 
+# Accumulation order of the float32 products.  "reference": torch's float32 ``@`` on this build, what the reference itself
+# runs (mat_mul.py:27; the order inside the BLAS kernel is not contractual).  "exact": the same float32 operands,
+# every product summed in float64 and rounded to float32 ONCE -- the correctly rounded value of each ``@``.  The distance
+# between the two is the reference's own float32 accumulation noise: tests/ use it to tell a result that differs from the
+# reference by its accumulation order from one that is wrong (tests/helpers.py: accumulation_noise_floor).
+ACCUM = "reference"
+
+
 def _mm(*mats: np.ndarray) -> np.ndarray:
     """Chained ``@`` left to right on float32 tensors, back to NumPy (mat_mul.py:17-31)."""
     acc = _t32(mats[0])
     for m in mats[1:]:
-        acc = acc @ _t32(m)
+        if ACCUM == "exact":
+            acc = (acc.double() @ _t32(m).double()).float()
+        else:
+            acc = acc @ _t32(m)
     return acc.numpy()
 
 
@@ -169,6 +180,11 @@ class Problem:
     impute: str = "binary"
     Z: Optional[np.ndarray] = None     # [N, k] float64 probe vectors (all_zb)
     dom: bool = False                  # RHE_DOM: a dominance estimate per bin after the additive ones
+    # "reference": every quirk of the reference kept.  "fixed": the model as its equations state it -- the LAST estimate is a
+    # heteroscedastic-noise (N x E) slot only when the model has one ("G+GxE+NxE"); for "G+GxE" every estimate's total is the
+    # sum over its blocks (genie.py:46-94 without base.py:467,472-481's overwrite).  This is the definition the product gives
+    # StreamingGENIE("G+GxE") (BASELINE config 5), which the reference cannot run (base_streaming.py:45-46 raises).
+    compat: str = "reference"
 
     def __post_init__(self):
         if self.cov is not None:
@@ -314,6 +330,8 @@ def precompute(p: Problem, streaming_compat: bool = False) -> State:
     for j, blk in enumerate(blocks):
         st.M[j] = st.M[jn] - blk.m                      # rhe.py:16 / streaming_rhe.py:16
     n_env = 1 if p.genie_model is not None else 0       # GENIE sets num_env = 1 for every genie_model (genie.py:18)
+    if p.compat == "fixed" and not p.has_nxe:
+        n_env = 0
     for e in range(ne):
         # streaming: aggregate skips the last num_env estimates and then fills the N x E slots from the same closed form
         # (base_streaming.py:24-58); only "G+GxE+NxE" reaches that code without an IndexError

@@ -153,6 +153,9 @@ struct pyrhe_engine {
     int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0;
     // kernels of the last sketch call (pyrhe_engine_info 6..8)
     int last_g1 = 0, last_g2 = 0, last_flow = 0;
+#ifdef PYRHE_DIAG
+    int diag_g1_plain_store = 0;    // diagnostic build only (tools/): never compiled into libpyrhe_sketch.so
+#endif
 };
 
 static constexpr int kMaxTiles = 2;  // 32 logical columns
@@ -501,7 +504,10 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         ProfScope ps(e, stream, 0);
         const int sm = e->opt_g1_split_major ? 1 : 0;      // grid order: which of (row group, sample split) is the fast index
         dim3 grid(sm ? splits : gx, sm ? gx : splits);
-        const int ua = splits > 1;
+        int ua = splits > 1;
+#ifdef PYRHE_DIAG
+        if (ua && e->diag_g1_plain_store) ua = 2;          // WRONG results: plain stores instead of atomics, to price the atomics
+#endif
         e->last_g1 = e->i8 ? 100 + e->nt8 : e->ntl;
         if (e->i8) {
             const size_t lds = (size_t)2 * g1_ch * 4 * e->nt8 * 1024;
@@ -841,6 +847,9 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
             e->opt_g2_splits = (int)value; break;
         case PYRHE_OPT_DOTS_GENERIC: e->opt_dots_generic = value != 0; break;
         case PYRHE_OPT_G1_SPLIT_MAJOR: e->opt_g1_split_major = value != 0; break;
+#ifdef PYRHE_DIAG
+        case 100: e->diag_g1_plain_store = value != 0; break;
+#endif
         default: return fail(PYRHE_EINVAL, "unknown option %d", option);
     }
     return PYRHE_OK;

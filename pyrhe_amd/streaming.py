@@ -305,6 +305,9 @@ class SketchRunner:
     def _ingest_stats(self):
         """Per-SNP observed sums / missing counts of the local rows (one extra read, once per cohort)."""
         if self._stats is None:
+            if self.geno.shape[0] == 0:          # a rank without local blocks (world > useful ranks)
+                self._stats = (np.zeros(0, np.int64), np.zeros(0, np.int64))
+                return self._stats
             s, nm = self.eng.block_stats(self.geno)
             self._stats = (s.cpu().numpy().astype(np.int64), nm.cpu().numpy().astype(np.int64))
         return self._stats

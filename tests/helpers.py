@@ -40,3 +40,30 @@ def oracle_problem(z, trait=0):
         p.env = c.env.reshape(-1, 1)
     p.Z = O.make_probe_vectors(p.seed, p.n_indv, p.k)
     return p, c
+
+
+def oracle_results(p, streaming=False):
+    """The oracle's result dict for a golden's problem, by model family."""
+    st = O.precompute(p, streaming_compat=streaming)
+    fn = O.genie_results if p.genie_model else (O.rhe_dom_results if p.dom else O.rhe_results)
+    return fn(p, st)
+
+
+def accumulation_noise_floor(z, keys, streaming=False):
+    """How far the REFERENCE's own results move when only the accumulation order of its float32 products changes: the oracle
+    in its reference order (torch float32 ``@``: bit-equal to the goldens) against the same float32 operands summed in
+    float64 and rounded once (``O.ACCUM = "exact"``).  Returned per result key, relative to the key's largest entry.  A
+    product result may differ from the golden by a small multiple of this and still be the same computation; GENIE's
+    normal equations amplify it 100x more than RHE's (measured: sigma^2 4e-6 vs 2e-8 of the largest component)."""
+    p, _ = oracle_problem(z)
+    out = {}
+    try:
+        ref = oracle_results(p, streaming)
+        O.ACCUM = "exact"
+        alt = oracle_results(p, streaming)
+    finally:
+        O.ACCUM = "reference"
+    for k in keys:
+        a, b = np.asarray(ref[k], float), np.asarray(alt[k], float)
+        out[k] = float(np.abs(a - b).max() / max(np.abs(a).max(), 1e-3))
+    return out

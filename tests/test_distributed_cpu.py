@@ -84,3 +84,62 @@ def test_streaming_q4_weighted_form_close_to_sequential(tmp_path):
     sig = np.array([est.solve_normal_equations(r0["T"][j], r0["q"][j].reshape(-1, 1)) for j in range(jn + 1)])
     assert np.allclose(sig[-1], z["ref_t0_res_sigma_ests_total"], rtol=1e-5)
     assert np.allclose(sig[:-1], z["ref_t0_sigma_jack"], rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# More ranks than the golden fixtures exercise: uneven shards (jn = 100 over 8 ranks: 13, ..., 13, 9), ranks without a
+# block (world > jn), covariates with the reference-compatible (weighted) UXXz -- all against the one-process run.
+# ----------------------------------------------------------------------------------------------------------------------
+def _synth_runner(n, m, jn, nbin, with_cov, compat):
+    from oracle import fixtures
+    from oracle import rhe_oracle as O
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner, shard_ranges
+    from tests.cpu_stub_engine import CpuStubEngine
+    c = fixtures.make_cohort("dist", n, m, seed=77, nbin=nbin, with_cov=with_cov)
+    y = c.pheno[:, 0] - c.pheno[:, 0].mean()
+    plan = BlockPlan(c.annot, jn)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    j0, j1 = shard_ranges(jn, world)[rank]
+    eng = CpuStubEngine(n, n)
+    r0 = plan.range(j0)[0] if j1 > j0 else 0
+    r1 = plan.range(j1 - 1)[1] if j1 > j0 else 0
+    geno = torch.zeros((r1 - r0, eng.pitch), dtype=torch.uint8)
+    geno[:, : c.packed.shape[1]] = torch.from_numpy(c.packed[r0:r1].copy())
+    Z = O.make_probe_vectors(0, n, 4)
+    runner = SketchRunner(eng, geno, plan, (j0, j1), n_orig=n, missing_indv=[], Z=Z, cov=c.cov, seed=0, streaming=True,
+                          compat=compat)
+    return runner, y, (j0, j1)
+
+
+def _synth_worker(rank, world, port, shape, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        runner, y, local = _synth_runner(*shape)
+        sysm = runner.run_trait(y)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), T=sysm.T, q=sysm.q, M=sysm.M, local=np.asarray(local))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape", [(4, (96, 300, 100, 2, 0, "reference")),
+                                         (8, (96, 300, 100, 3, 3, "reference")),      # 13 x 7 + 9 blocks, weighted UXXz (Q4)
+                                         (8, (96, 300, 100, 1, 3, "fixed")),
+                                         (4, (64, 90, 3, 2, 2, "reference")),         # world > jn: one rank has no block
+                                         (8, (64, 100, 10, 1, 0, "reference"))])      # ceil rule: ranks 5..7 empty
+def test_many_ranks_uneven_and_empty_shards_equal_one_rank(world, shape, tmp_path):
+    from pyrhe_amd.streaming import shard_ranges
+    mp.spawn(_synth_worker, args=(world, _free_port(), shape, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    jn = shape[2]
+    assert [tuple(p["local"]) for p in parts] == shard_ranges(jn, world)
+    sizes = [b - a for a, b in shard_ranges(jn, world)]
+    assert sum(sizes) == jn and (world <= jn or 0 in sizes)
+    for p in parts[1:]:
+        assert np.array_equal(parts[0]["T"], p["T"]) and np.array_equal(parts[0]["q"], p["q"])     # every rank holds all systems
+    runner, y, _ = _synth_runner(*shape)                                                            # world = 1 in this process
+    one = runner.run_trait(y)
+    assert np.array_equal(one.M, parts[0]["M"])
+    assert np.allclose(one.T, parts[0]["T"], rtol=1e-11, atol=0) and np.allclose(one.q, parts[0]["q"], rtol=1e-12, atol=0)

@@ -42,3 +42,20 @@ def test_bench_two_ranks_equal_one_rank(extra):
     # the cross-rank float64 sum changes the summation order only
     assert np.allclose(a["config"]["sigma_total"], b["config"]["sigma_total"], rtol=1e-9)
     assert np.allclose(a["config"]["sigma_se"], b["config"]["sigma_se"], rtol=1e-7)
+
+
+def test_two_ranks_without_a_seed_agree(tmp_path):
+    """seed=None (run_rhe.py's default) under a multi-rank launch: rank 0's clock-derived seed is broadcast, so every rank
+    draws the same probe vectors and generated annotation (written once, by rank 0); both ranks report the same estimates."""
+    from oracle import fixtures
+    c = fixtures.make_cohort("noseed", 500, 360, seed=9)
+    paths = fixtures.write_cohort_files(c, str(tmp_path))
+    env = dict(os.environ, PYRHE_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_port()), os.path.join(REPO, "tests", "dist_model_worker.py"),
+                        str(tmp_path), paths["geno"], paths["pheno"]], cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = (json.load(open(tmp_path / f"rank{i}.json")) for i in (0, 1))
+    assert a["seed"] == b["seed"] and a["zsum"] == b["zsum"] and a["len_bin"] == b["len_bin"] and sum(a["len_bin"]) == 360
+    assert a["sigma"] == b["sigma"] and a["se"] == b["se"]
+    assert np.all(np.isfinite(a["sigma"])) and np.all(np.isfinite(a["se"]))

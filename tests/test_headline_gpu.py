@@ -1,0 +1,171 @@
+"""Oracle parity of the EXACT kernels and flows the headline number comes from, at the sizes where the engine selects them.
+
+bench.py's `value` is measured on ``gemm1_i8_kernel<3, .., VC>`` + ``gemm2_i8p_kernel<1>`` in the segmented flow (several
+jackknife blocks per engine call), value-coded genotypes from the device generator, k = 10, one bin.  Those instantiations
+only engage for large cohorts / batched calls, so the small golden fixtures never reach them.  Here the same runner
+configuration as bench.py is driven at N = 500 000 (BASELINE config 3's cohort size), N = 50 000 (config 2) and N = 200 000
+with 8 bins + 10 covariates (config 4's shape: four-tile GEMM 1, two-column-group packed GEMM 2), on few enough SNPs that the
+reference-order oracle (oracle/rhe_oracle.py, torch CPU float32 GEMV pairs) finishes in seconds on the box's host cores.
+
+Tolerances (the north star's): per-block X X^T z and ||X^T y||^2 within 5e-6 of the block's largest entry (float32
+accumulation-order noise of the reference itself); sigma^2 and jackknife SE within 1e-5 relative.
+Every test asserts, through pyrhe_engine_info, WHICH kernels ran -- a silent fall to the fp16 kernels fails the test.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import plink, synth
+from oracle import rhe_oracle as O
+
+pytestmark = pytest.mark.gpu
+SEED = 20251212          # bench.py's SYNTH_SEED
+
+
+def _setup(n, m, jn, k, nbin=1, n_cov=0, row0=0):
+    from pyrhe_amd import engine
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner, engine_capacity, n_engines_needed
+    dev = torch.device("cuda", 0)
+    geno = engine.recode_rows(engine.synth_genotypes(m, n, SEED, row0, dev), "value")      # as bench.py: generated, then value-coded
+    g = synth.synth_rows(SEED, row0, m, n)                                                  # CPU twin of the generator
+    annot = np.zeros((m, nbin), np.int64)
+    annot[np.arange(m), (np.arange(m) * 7 + 3) % nbin] = 1
+    rng = np.random.default_rng(1)
+    y = rng.normal(size=n)
+    # a heritable part so that sigma^2_g is not statistically zero (relative errors of ~0 +- SE mean nothing)
+    mu = g[:: max(1, m // 50)].mean(axis=1, keepdims=True)
+    Xs = (g[:: max(1, m // 50)] - mu) / np.sqrt(mu * (1 - mu / 2))
+    y = y + Xs.T @ rng.normal(0, 0.2, Xs.shape[0])
+    y -= y.mean()
+    cov = None
+    if n_cov:
+        cov = np.concatenate([np.ones((n, 1)), np.random.default_rng(2).normal(size=(n, n_cov - 1))], axis=1)
+    p = O.Problem(packed=plink.encode_bed_rows(g), n_indv_orig=n, annot=annot, pheno=y.reshape(-1, 1), n_jack=jn, k=k, seed=0, cov=cov)
+    p.Z = O.make_probe_vectors(0, n, k)
+    plan = BlockPlan(annot, jn)
+    engs = []
+    for _ in range(n_engines_needed(k, cov is not None, False)):
+        e_ = engine.SketchEngine(n, n, max_entries=engine_capacity(plan), precision="i8x3", device=dev, sub_snps=engine_capacity(plan))
+        e_.set_coding("value")
+        engs.append(e_)
+    runner = SketchRunner(engs, geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=p.Z, cov=cov, seed=0, streaming=False,
+                          compat="fixed")
+    return p, runner, engs
+
+
+def _check(p, runner, engs, want_path, blocks_per_call):
+    from pyrhe_amd import estimate as est
+    jn, N, nb = p.n_jack, p.n_indv, p.nbin
+    assert min(runner._blocks_per_call(), jn) == blocks_per_call         # the blocks of this cohort go in ONE engine call
+    runner.begin_trait(p.pheno[:, 0], check_missing=False)
+    runner.pass1()
+    torch.cuda.synchronize()
+    path = engs[0].last_path()
+    assert path == want_path, path
+    st = O.precompute(p)                                      # the oracle: every block in the reference's operation order
+    use_cov = p.cov is not None
+    for j in range(jn):
+        A, C, r = runner._block_estimates(*runner._stored_block(j))
+        blk = st.blocks[j]
+        for b in range(nb):
+            ref = blk.XXz[b]
+            scale = np.abs(ref).max()
+            got = A[b, :, :N].cpu().numpy()
+            assert np.abs(got - ref).max() <= 5e-6 * scale, ("XXz", j, b, np.abs(got - ref).max() / scale)
+            assert abs(float(r[b, 0]) - blk.yXXy[b]) <= 1e-5 * abs(blk.yXXy[b]), ("yXXy", j, b)
+            if use_cov:
+                refc = blk.XXUz[b]
+                gotc = C[b, :, :N].cpu().numpy()
+                assert np.abs(gotc - refc).max() <= 5e-6 * max(np.abs(refc).max(), 1e-30), ("XXUz", j, b)
+        assert not A[:, :, N:].any()
+    sysm = runner.pass2()
+    sig = est.solve_all(sysm.T, sysm.q)
+    se = np.asarray(est.jackknife_se(sig[:-1], jn))
+    ref = O.rhe_results(p, st)
+    assert np.array_equal(sysm.M, st.M)
+    # 1e-5 relative per entry; a component below 5 % of the largest one (a bin whose sigma^2 is statistically zero) is
+    # judged against 5 % of the largest instead of against itself
+    floor = lambda v: np.maximum(np.abs(v), 0.05 * np.abs(v).max())
+    rel = np.abs(sig[-1] - ref["sigma_ests_total"]) / floor(ref["sigma_ests_total"])
+    rel_se = np.abs(se - ref["sig_errs"]) / floor(ref["sig_errs"])
+    assert rel.max() <= 1e-5, (rel, sig[-1], ref["sigma_ests_total"])
+    assert rel_se.max() <= 1e-5, (rel_se, se, ref["sig_errs"])
+    for e_ in engs:
+        e_.close()
+
+
+def test_headline_kernels_at_n500k_vs_oracle():
+    """BASELINE config 3's cohort size: three 200-SNP blocks in ONE engine call (bench.py batches three 10 000-SNP blocks)."""
+    p, runner, engs = _setup(500_000, 600, 3, 10)
+    _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3)
+
+
+def test_headline_kernels_at_n50k_vs_oracle():
+    """BASELINE config 2's cohort size: three 1000-SNP blocks per call, the batched small-cohort flow of bench.py."""
+    p, runner, engs = _setup(50_000, 3000, 3, 10, row0=17)
+    _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3)
+
+
+def test_c4_shape_8bins_covariates_at_n200k_vs_oracle():
+    """BASELINE config 4's shape (8 bins + 10 covariates incl. the intercept): 21 right-hand columns = 64 packed digit rows =
+    the four-tile int8 GEMM 1, 20 sketch columns = the two-column-group packed int8 GEMM 2; XXz, XXUz and yXXy per block."""
+    p, runner, engs = _setup(200_000, 1200, 3, 10, nbin=8, n_cov=10, row0=5)
+    _check(p, runner, engs, {"gemm1": 104, "gemm2": 12, "segmented": True}, blocks_per_call=3)
+
+
+def test_blocks_beyond_one_call_are_split_into_row_pieces():
+    """A jackknife block with more rows than one engine call addresses (32-bit row byte offsets: N = 500k, over 34 308 SNPs)
+    goes as row sub-ranges whose later pieces accumulate.  Forced here with a small row limit: same systems as unsplit."""
+    from pyrhe_amd import engine
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner
+    dev = torch.device("cuda", 0)
+    n, m, jn, k = 3000, 900, 3, 10
+    geno = engine.recode_rows(engine.synth_genotypes(m, n, SEED, 41, dev), "value")
+    rng = np.random.default_rng(6)
+    annot = np.zeros((m, 3), np.int64)
+    annot[np.arange(m), rng.integers(0, 3, m)] = 1
+    annot[rng.choice(m, 60, replace=False), 1] = 1
+    plan = BlockPlan(annot, jn)
+    np.random.seed(0)
+    Z = np.random.randn(n, k)
+    y = rng.normal(size=n); y -= y.mean()
+    cov = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, 2))], axis=1)
+    out = []
+    for limit, recompute in ((None, False), (128, False), (77, True)):
+        eng = engine.SketchEngine(n, n, plan.max_block, device=dev)
+        eng.set_coding("value")
+        runner = SketchRunner(eng, geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True,
+                              compat="reference", recompute_pass2=recompute)
+        runner.row_limit = limit
+        out.append(runner.run_trait(y, check_missing=False))
+        eng.close()
+    for o in out[1:]:
+        assert np.abs(o.T - out[0].T).max() <= 2e-6 * np.abs(out[0].T).max()
+        assert np.allclose(o.q, out[0].q, rtol=2e-6)
+
+
+def test_projector_kernel_vs_oracle_float32_chain():
+    """pyrhe_engine_apply_projector (Base._compute_UXXz, base.py:407-408) against the oracle's float32
+    mat_mul chain W (Q (W^T v)) and against a float64 evaluation."""
+    from pyrhe_amd import engine
+    dev = torch.device("cuda", 0)
+    n, c, rows = 20_000, 11, 7
+    rng = np.random.default_rng(8)
+    W = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, c - 1))], axis=1)
+    Q = np.linalg.pinv(W.T @ W)
+    v = rng.normal(size=(rows, n)) * 1000.0
+    eng = engine.SketchEngine(n, n, 64, device=dev)
+    n_pad = eng.n_pad
+    x = torch.zeros((rows, n_pad), dtype=torch.float64, device=dev)
+    x[:, :n] = torch.from_numpy(v).to(dev)
+    Wt = torch.zeros((c, n_pad), dtype=torch.float32, device=dev)
+    Wt[:, :n] = torch.from_numpy(W.T.astype(np.float32)).to(dev)
+    got = eng.apply_projector(x, Wt, torch.from_numpy(Q.astype(np.float32)).to(dev)).cpu().numpy()
+    assert not got[:, n:].any()
+    exact = (W @ (Q @ (W.T @ v.T))).T
+    scale = np.abs(exact).max()
+    for r in range(rows):
+        ref32 = O.project_U(v[r], W, Q)
+        assert np.abs(got[r, :n] - ref32).max() <= 2e-6 * scale
+        assert np.abs(got[r, :n] - exact[r]).max() <= 2e-6 * scale
+    eng.close()
