@@ -92,7 +92,14 @@ def cpu_baseline(n_indv: int, k: int, n_blocks: int, block_snps: int, gpu_check=
         blk = O.sketch_block(p, j, reseed=False)
         dt += time.perf_counter() - t0
         if gpu_check is not None:
-            for key, v in gpu_check(j, blk).items():
+            blk_x = None
+            if j < 2:          # untimed: the same block with the float32 products summed exactly (the reference's own
+                try:           # accumulation noise is |reference order - exact|; at N = 500k it is ~6e-6 of the block maximum)
+                    O.ACCUM = "exact"
+                    blk_x = O.sketch_block(p, j, reseed=False)
+                finally:
+                    O.ACCUM = "reference"
+            for key, v in gpu_check(j, blk, blk_x).items():
                 worst[key] = max(worst.get(key, 0.0), float(v))
     out = {"value": n_snps / dt, "unit": "SNPs/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"pass-1 body of the reference-order oracle on the first {n_blocks} x {block_snps} SNPs x N={n_indv}, k={k} "
@@ -372,12 +379,21 @@ def main():
             chk_eng.set_rhs(padded(make_probe(N, k).T), padded(y_b.T), keep)
         ent = torch.arange(bs, dtype=torch.int32, device=dev)
 
-        def gpu_check(j, blk):
+        def gpu_check(j, blk, blk_x):
+            """Deviations of the engine's block sketch, relative to the block's largest entry: from the oracle in the
+            reference's summation order, and (first two blocks) from the exactly summed one, beside the distance between the
+            two oracles = the reference's own float32 accumulation noise."""
             sk, nm, _ = chk_eng.sketch_block(geno[j * bs:(j + 1) * bs], ent, [0, bs])
             got = sk[0, :, :N].double().cpu().numpy()
             ref = blk.XXz[0]
-            return {"XXz_rel_of_block_max": np.abs(got - ref).max() / np.abs(ref).max(),
-                    "yXXy_rel": abs(float(nm[0, 0]) - blk.yXXy[0]) / abs(blk.yXXy[0])}
+            sc = np.abs(ref).max()
+            out_ = {"XXz_engine_vs_reference_order": np.abs(got - ref).max() / sc,
+                    "yXXy_engine_vs_reference_order": abs(float(nm[0, 0]) - blk.yXXy[0]) / abs(blk.yXXy[0])}
+            if blk_x is not None:
+                out_["XXz_engine_vs_exact_sum"] = np.abs(got - blk_x.XXz[0]).max() / sc
+                out_["XXz_reference_order_vs_exact_sum"] = np.abs(ref - blk_x.XXz[0]).max() / sc
+                out_["yXXy_engine_vs_exact_sum"] = abs(float(nm[0, 0]) - blk_x.yXXy[0]) / abs(blk_x.yXXy[0])
+            return out_
         try:
             out["cpu_baseline"] = cpu_baseline(N, k, nblk, bs, gpu_check if can_check else None)
             if can_check:

@@ -154,7 +154,7 @@ struct pyrhe_engine {
     // kernels of the last sketch call (pyrhe_engine_info 6..8)
     int last_g1 = 0, last_g2 = 0, last_flow = 0;
 #ifdef PYRHE_DIAG
-    int diag_g1_plain_store = 0;    // diagnostic build only (tools/): never compiled into libpyrhe_sketch.so
+    int diag_g1_plain_store = 0, diag_g1_no_barrier = 0;    // diagnostic build only (tools/): never compiled into libpyrhe_sketch.so
 #endif
 };
 
@@ -504,15 +504,16 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         ProfScope ps(e, stream, 0);
         const int sm = e->opt_g1_split_major ? 1 : 0;      // grid order: which of (row group, sample split) is the fast index
         dim3 grid(sm ? splits : gx, sm ? gx : splits);
-        int ua = splits > 1;
+        int ua = splits > 1, g1_diag = 0;
 #ifdef PYRHE_DIAG
         if (ua && e->diag_g1_plain_store) ua = 2;          // WRONG results: plain stores instead of atomics, to price the atomics
+        g1_diag = e->diag_g1_no_barrier ? 1 : 0;           // WRONG results: no step barrier, to price the barrier
 #endif
         e->last_g1 = e->i8 ? 100 + e->nt8 : e->ntl;
         if (e->i8) {
             const size_t lds = (size_t)2 * g1_ch * 4 * e->nt8 * 1024;
-#define G1I(NT_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm); \
-                                  else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm); } while (0)
+#define G1I(NT_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag); \
+                                  else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag); } while (0)
 #define G1J(NT_) do { if (gv == 0) { if (fill) G1I(NT_, true, 0); else G1I(NT_, false, 0); } \
                       else if (gv == 1) { if (fill) G1I(NT_, true, 1); else G1I(NT_, false, 1); } \
                       else { if (fill) G1I(NT_, true, 2); else G1I(NT_, false, 2); } } while (0)
@@ -849,6 +850,7 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
         case PYRHE_OPT_G1_SPLIT_MAJOR: e->opt_g1_split_major = value != 0; break;
 #ifdef PYRHE_DIAG
         case 100: e->diag_g1_plain_store = value != 0; break;
+        case 101: e->diag_g1_no_barrier = value != 0; break;
 #endif
         default: return fail(PYRHE_EINVAL, "unknown option %d", option);
     }

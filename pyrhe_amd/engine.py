@@ -156,7 +156,7 @@ def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28) -
 CODINGS = {"plink": 0, "value": 1}
 # PYRHE_OPT_* of include/pyrhe_sketch.h: launch-shape knobs, every value computes the same results
 OPTIONS = {"g1_workgroups": 1, "g2_packed": 2, "g2_iw": 3, "g2_splits": 4, "dots_generic": 5, "g1_split_major": 6,
-           "diag_g1_plain_store": 100}     # 100+: only in the diagnostic build (PYRHE_LIB=...libpyrhe_sketch_diag.so), wrong results
+           "diag_g1_plain_store": 100, "diag_g1_no_barrier": 101}     # 100+: only in the diagnostic build (PYRHE_LIB=...libpyrhe_sketch_diag.so), wrong results
 
 
 def recode_rows(packed: torch.Tensor, to: str = "value") -> torch.Tensor:
@@ -242,6 +242,7 @@ class SketchEngine:
             _check(self.lib.pyrhe_engine_create(self.device.index, self.n_keep, self.pitch, self.max_entries,
                                                 PRECISIONS[precision], int(sub_snps), C.byref(h)), "pyrhe_engine_create")
         self._h = h
+        self.n_cu = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
         self.n_sketch = 0
         self.n_norm = 0
         self._keep = None

@@ -365,6 +365,9 @@ class SketchRunner:
         by_entries = cap // max(self.plan.max_block, 1)
         by_bytes = self._row_limit() // max(self.plan.max_block, 1)
         by_lists = MAX_SEGMENTS // max(self.plan.n_bin, 1)
+        # (Choosing the batch so that GEMM 2's launch fills whole rounds of resident workgroups -- N = 50k: 10 blocks = 490
+        # workgroups in one round of 512 instead of 13 = 637 in two -- was measured: GEMM 2 1.34 -> 1.21 ms per pass, GEMM 1
+        # 1.66 -> 1.77 ms with two more launches: no gain; the largest batch stays.)
         return max(1, min(by_entries, by_bytes, by_lists))
 
     def _row_limit(self) -> int:
@@ -637,8 +640,10 @@ class SketchRunner:
             return t
 
         def z_part(lst):
-            """The XXz columns (group Z) of weighted totals as contiguous tensors: all that quirk Q4 needs of them."""
-            return {p_: lst[p_][:, c0:c0 + nc].contiguous() for p_, c0, _, nc in self.loc["Z"]}
+            """The XXz columns (groups Z and e.Z) of weighted totals as contiguous tensors, chunk by chunk: all that quirk Q4
+            needs of them (the U Z columns are not sent)."""
+            return {name: [lst[p_][:, c0:c0 + nc].contiguous() for p_, c0, _, nc in self.loc[name]]
+                    for name in (("Z", "eZ") if self.n_gxe else ("Z",))}
 
         tot_skd = tot_nmd = w_sk = w_skd = None
         if not self.one_slot:
@@ -683,8 +688,9 @@ class SketchRunner:
                 w_sk, w_skd = z_part(wf), (z_part(wfd) if self.dom else None)
         if self.world > 1:
             for d_ in (w_sk, w_skd):
-                for t in (d_ or {}).values():
-                    reduce_async(t)
+                for chunks in (d_ or {}).values():
+                    for t in chunks:
+                        reduce_async(t)
             small = tot_nm + (tot_nmd or [])                       # [nbin, n_norm] each: one packed buffer
             flat = torch.cat([t.reshape(-1) for t in small])
             self._allreduce(flat)
@@ -702,10 +708,12 @@ class SketchRunner:
             # quirk Q4 (streaming_rhe.py:18-21): the reference applies U to the RUNNING sum of XXz after every block;
             # U is linear, so sum_j U(sum_{i<=j} XXz_i) = U(sum_i (jn - i) XXz_i): one weighted block sum, one U
             # (float32 rounding order differs from the block-by-block application at the 1e-7 level)
-            cat = lambda d_: torch.cat([d_[p_] for p_, _, _, _ in self.loc["Z"]], dim=1) if len(self.loc["Z"]) > 1 else d_[self.loc["Z"][0][0]]
-            wsum = cat(w_sk)
+            cat = lambda chunks: torch.cat(chunks, dim=1) if len(chunks) > 1 else chunks[0]
+            wsum = cat(w_sk["Z"])                                  # the estimates in _block_estimates' order: G bins,
             if self.dom:
-                wsum = torch.cat([wsum, cat(w_skd)], dim=0)
+                wsum = torch.cat([wsum, cat(w_skd["Z"])], dim=0)   # then dominance bins
+            if self.n_gxe:
+                wsum = torch.cat([wsum, cat(w_sk["eZ"]) * self.env_pad], dim=0)      # or G x E bins: e . (X X^T (e . z))
             wsum = wsum.contiguous()
         D_tot = self._apply_U(wsum if q4 else tot_A, f32=True) if use_cov else None     # a10: pyrhe_engine_apply_projector
         self.tot_A, self.tot_C, self.tot_r, self.D_tot = tot_A, tot_C, tot_r, D_tot

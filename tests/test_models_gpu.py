@@ -113,11 +113,11 @@ def test_f16_mode_close(tmp_path):
 def test_genie_matches_reference(name, tmp_path):
     """GENIE G+GxE(+NxE), with and without covariates (two engine passes when the columns exceed one engine): M, T, the
     result dict and the log grammar.  The G+GxE goldens include the reference's last-estimate quirk, which makes the system
-    ill-conditioned (|sigma| up to 22).  Numbers are compared per reported vector, relative to its largest entry, at the north
-    star's 1e-5 -- or 4x the reference's OWN float32 accumulation-noise floor (tests/helpers.accumulation_noise_floor, measured
-    here on the CPU: sigma^2 moves by up to 4e-6 of its largest component when only the summation order of the reference's
-    float32 products changes), whichever is larger."""
-    from tests.helpers import RESULT_KEYS_GENIE, accumulation_noise_floor
+    ill-conditioned (|sigma| up to 22).  Numbers are compared per reported vector, relative to its largest entry (components
+    that are statistically zero, e.g. -0.0013 +- 0.03, have no meaningful per-entry relative error), at the north star's 1e-5.
+    Measured on MI355X: every key deviates by <= 1.5e-6, the size of the reference's OWN float32 accumulation noise
+    (tests/test_oracle_golden.py::test_reference_accumulation_noise_floor: up to 4e-6 for GENIE, 2e-8 for RHE)."""
+    from tests.helpers import RESULT_KEYS_GENIE
     z = load_golden(name)
     c = fixtures.cohort_from_npz(z)
     paths = fixtures.write_cohort_files(c, str(tmp_path))
@@ -127,13 +127,11 @@ def test_genie_matches_reference(name, tmp_path):
     assert np.array_equal(m.M, z["ref_t0_M"])
     Tref = z["ref_t0_T"]
     assert np.abs(m.systems.T - Tref).max() <= 5e-6 * np.abs(Tref).max()
-    floor = accumulation_noise_floor(z, RESULT_KEYS_GENIE)
     for k in RESULT_KEYS_GENIE:
-        # (components that are statistically zero, e.g. -0.0013 +- 0.03, have no meaningful per-entry relative error)
         r = z["ref_t0_res_" + k]
         dev = np.abs(np.asarray(res[k], float) - r).max() / max(np.abs(r).max(), 1e-3)
-        print(f"[{name}] {k}: deviation {dev:.1e} of the largest entry (reference noise floor {floor[k]:.1e})")
-        assert dev <= max(1e-5, 4 * floor[k]), (k, dev, floor[k])
+        print(f"[{name}] {k}: deviation {dev:.1e} of the largest entry")
+        assert dev <= RTOL, (k, dev)
     ref_lines = str(z["ref_t0_log"]).splitlines()
     got_lines = "".join(log.msgs[n0:]).splitlines()
     strip = lambda ls: [re.sub(r"-?\d+\.\d+(e-?\d+)?|nan", "#", l) for l in ls]
@@ -194,7 +192,7 @@ def test_rhe_dom_matches_reference(name, precision, tmp_path):
 def test_streaming_genie_matches_reference(tmp_path):
     """StreamingGENIE("G+GxE+NxE") + covariates against the reference's one-worker streaming run (pass-1 / pass-2 bodies
     of streaming_genie.py, N x E from the streaming aggregate, running-sum UXXz)."""
-    from tests.helpers import RESULT_KEYS_GENIE, accumulation_noise_floor
+    from tests.helpers import RESULT_KEYS_GENIE
     z = load_golden("sgenie_gxe_nxe_cov")
     c = fixtures.cohort_from_npz(z)
     paths = fixtures.write_cohort_files(c, str(tmp_path))
@@ -202,12 +200,10 @@ def test_streaming_genie_matches_reference(tmp_path):
     n0 = len(log.msgs)
     res = m(trait=0)
     assert np.array_equal(m.M, z["ref_t0_M"])
-    floor = accumulation_noise_floor(z, RESULT_KEYS_GENIE, streaming=True)      # the reference's own float32 summation-order noise
-    bound = lambda k: max(1e-5, 4 * floor[k])
-    assert np.abs(m.sigma_est_jackknife - z["ref_t0_sigma_jack"]).max() <= bound("sigma_ests_total") * np.abs(z["ref_t0_sigma_jack"]).max()
+    assert np.abs(m.sigma_est_jackknife - z["ref_t0_sigma_jack"]).max() <= RTOL * np.abs(z["ref_t0_sigma_jack"]).max()
     for k in RESULT_KEYS_GENIE:
         r = z["ref_t0_res_" + k]
-        assert np.abs(np.asarray(res[k], float) - r).max() <= bound(k) * max(np.abs(r).max(), 1e-3), k
+        assert np.abs(np.asarray(res[k], float) - r).max() <= RTOL * max(np.abs(r).max(), 1e-3), k
     strip = lambda ls: [re.sub(r"-?\d+\.\d+(e-?\d+)?|nan", "#", l) for l in ls]
     assert strip("".join(log.msgs[n0:]).splitlines()) == strip(str(z["ref_t0_log"]).splitlines())
 
