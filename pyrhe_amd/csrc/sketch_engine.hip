@@ -507,7 +507,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         int ua = splits > 1, g1_diag = 0;
 #ifdef PYRHE_DIAG
         if (ua && e->diag_g1_plain_store) ua = 2;          // WRONG results: plain stores instead of atomics, to price the atomics
-        g1_diag = e->diag_g1_no_barrier ? 1 : 0;           // WRONG results: no step barrier, to price the barrier
+        g1_diag = e->diag_g1_no_barrier;                    // WRONG results: bit 0 no step barrier, bit 1 no wait for the R image
 #endif
         e->last_g1 = e->i8 ? 100 + e->nt8 : e->ntl;
         if (e->i8) {
@@ -850,7 +850,7 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
         case PYRHE_OPT_G1_SPLIT_MAJOR: e->opt_g1_split_major = value != 0; break;
 #ifdef PYRHE_DIAG
         case 100: e->diag_g1_plain_store = value != 0; break;
-        case 101: e->diag_g1_no_barrier = value != 0; break;
+        case 101: e->diag_g1_no_barrier = (int)value; break;
 #endif
         default: return fail(PYRHE_EINVAL, "unknown option %d", option);
     }
