@@ -2,7 +2,7 @@
 # Cross-check sweep on the GPU box: unusual shapes through bench.py --verify, the default i8x3 (packed int8 kernels,
 # segmented flow) against f16x2 (fp16 kernels) -- two independent kernel families must agree to ~1e-6 on sigma^2 and SEs.
 fmt='import json,sys; d=json.loads(sys.stdin.read()); c=d["config"]; print(sys.argv[1], [round(x,9) for x in c["sigma_total"][:4]], [round(x,9) for x in c["sigma_se"][:4]])'
-run() { tag="$1"; shift; for p in i8x3 f16x2; do timeout -k 10 300 python bench.py --precision $p "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-alt --verify 2>/dev/null | tail -1 | python -c "$fmt" "$tag/$p"; done; }
+run() { tag="$1"; shift; for p in i8x3 f16x2; do timeout -k 10 300 python bench.py --precision $p "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-alt --no-cross-check --verify 2>/dev/null | tail -1 | python -c "$fmt" "$tag/$p"; done; }
 run "blocks>sub_snps" --n-indv 30000 --n-snp 200000 --jn 3
 run "tiny-blocks" --n-indv 100000 --n-snp 100000 --jn 100
 run "24bins" --n-indv 50000 --n-snp 120000 --jn 20 --n-bin 24
