@@ -154,7 +154,8 @@ struct pyrhe_engine {
     // kernels of the last sketch call (pyrhe_engine_info 6..8)
     int last_g1 = 0, last_g2 = 0, last_flow = 0;
 #ifdef PYRHE_DIAG
-    int diag_g1_plain_store = 0, diag_g1_no_barrier = 0;    // diagnostic build only (tools/): never compiled into libpyrhe_sketch.so
+    int diag_g1_plain_store = 0, diag_g1_no_barrier = 0;
+    long long* diag_g1_stats = nullptr;   // device uint64[6]: cycles per loop phase + waves, summed over the launches    // diagnostic build only (tools/): never compiled into libpyrhe_sketch.so
 #endif
 };
 
@@ -490,10 +491,14 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
 
     // ---- GEMM 1 of one entry list, genotype view gv, into Pbuf (zeroed by the caller)
     auto run_gemm1 = [&](int gv, const int32_t* rows, int n, float* Pbuf, float* Pbuf2 = nullptr) {
-        const int gx = (n + 255) / 256;
+        // waves per workgroup (they share one staged R slice).  6 and 12 were built and measured in round 2 (template parameter
+        // WAVES of gemm1_i8_kernel: a third of the R traffic at 12) and are slower -- 31.7 / 28.9 ms per pass against 27.6 at
+        // the headline shape: the barrier of a 12-wave workgroup costs 32 % of its waves' time.
+        constexpr int g1_waves = 4;
+        const int gx = (n + 64 * g1_waves - 1) / (64 * g1_waves);
         const int g1_ch = (e->i8 && e->nt8 > 3) ? 1 : 2;  // 256-sample chunks per step (see gemm1_i8_kernel)
         const int n_steps = n_chunks / g1_ch;             // pitch is a multiple of 256 B = 4 chunks
-        const int g1_wgs = e->opt_g1_wgs;                 // target workgroups per launch
+        const int g1_wgs = std::max(1, e->opt_g1_wgs * 4 / g1_waves);     // target workgroups per launch (the knob counts 4-wave workgroups)
         int splits = (g1_wgs + gx - 1) / gx;
         splits = std::max(1, std::min(splits, n_steps / 4 > 0 ? n_steps / 4 : 1));
         int cps = (n_steps + splits - 1) / splits;        // steps per split, even (n_steps is even)
@@ -508,6 +513,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
 #ifdef PYRHE_DIAG
         if (ua && e->diag_g1_plain_store) ua = 2;          // WRONG results: plain stores instead of atomics, to price the atomics
         g1_diag = e->diag_g1_no_barrier;                    // WRONG results: bit 0 no step barrier, bit 1 no wait for the R image
+        if (e->diag_g1_stats && gv != 2) { g1_diag |= 4; Pbuf2 = reinterpret_cast<float*>(e->diag_g1_stats); }   // bit 2: phase cycle account
 #endif
         e->last_g1 = e->i8 ? 100 + e->nt8 : e->ntl;
         if (e->i8) {
@@ -851,6 +857,7 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
 #ifdef PYRHE_DIAG
         case 100: e->diag_g1_plain_store = value != 0; break;
         case 101: e->diag_g1_no_barrier = (int)value; break;
+        case 102: e->diag_g1_stats = reinterpret_cast<long long*>(value); break;
 #endif
         default: return fail(PYRHE_EINVAL, "unknown option %d", option);
     }
