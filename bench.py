@@ -246,7 +246,9 @@ def main():
     dom = "gemm2_kernel" if g2 >= g1 else "gemm1_kernel"
     dom_ms = max(g1, g2)
     g1_i8 = path["gemm1"] >= 100
-    g1_name = f"gemm1_i8_kernel<{path['gemm1'] - 100}>" if g1_i8 else f"gemm1_kernel<{path['gemm1']}>"
+    g1_tiles_i8 = path["gemm1"] % 100
+    g1_name = (f"gemm1_i8w_kernel<{g1_tiles_i8}>" if path["gemm1"] >= 200 else f"gemm1_i8_kernel<{g1_tiles_i8}>") if g1_i8 \
+        else f"gemm1_kernel<{path['gemm1']}>"
     g2_packed = path["gemm2"] in (11, 12)
     g2_name = f"gemm2_i8p_kernel<{path['gemm2'] - 10}>" if g2_packed else "gemm2_kernel"
     dom_name = g2_name if dom == "gemm2_kernel" else g1_name
@@ -284,7 +286,7 @@ def main():
         parts = 1 if args.precision in ("f16", "f16e", "i8f16") else 2
         mfma_ops, mfma_peak = rows_per_launch * 2.0 * n_pad * 16 * tiles_out * parts, 2500.0       # fp16 dense TFLOP/s
     else:
-        g1_tiles = path["gemm1"] - 100 if g1_i8 else tiles_in * (2 if args.precision == "f16x2" else 1)
+        g1_tiles = g1_tiles_i8 if g1_i8 else tiles_in * (2 if args.precision == "f16x2" else 1)
         mfma_ops = rows_per_launch * 2.0 * n_pad * 16 * g1_tiles
         mfma_peak = 5000.0 if g1_i8 else 2500.0                                                    # int8 dense TOP/s
     mfma_tops = mfma_ops / (dom_ms / launches * 1e-3) / 1e12 if dom_ms > 0 else 0.0

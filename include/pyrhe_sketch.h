@@ -245,7 +245,8 @@ int pyrhe_synth_genotypes(uint8_t* packed, int64_t n_rows, int64_t pitch, int64_
 
 /* engine introspection: 0 n_pad, 1 sub_snps, 2 n_tiles_in, 3 n_sketch, 4 n_norm, 5 workspace bytes;
  * which kernels the LAST sketch call launched (so a parity test can assert the path it checked is the path it meant):
- *   6 GEMM 1: 100 + tiles for gemm1_i8_kernel<tiles>, tiles for gemm1_kernel<tiles> (fp16), 0 before any call
+ *   6 GEMM 1: 100 + tiles for gemm1_i8_kernel<tiles>, 200 + tiles for gemm1_i8w_kernel<tiles>, tiles for gemm1_kernel<tiles>
+ *             (fp16), 0 before any call
  *   7 GEMM 2: 11 / 12 gemm2_i8p_kernel<NG = 1 / 2>, 1 gemm2_kernel (fp16 hi+lo or single), 0 none (no sketch columns)
  *   8 flow  : 1 segmented (one GEMM 1 over the concatenated lists, GEMM 2 by segment), 0 one kernel triple per list */
 int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
@@ -261,6 +262,8 @@ int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
 #define PYRHE_OPT_DOTS_GENERIC 5  /* 1: pyrhe_engine_loo_dots always takes the register-tiled generic kernel        */
 #define PYRHE_OPT_G1_SPLIT_MAJOR 6 /* 1: GEMM 1 grid with the sample split as the fast index (co-resident workgroups
                                       share rows); default 0                                                        */
+#define PYRHE_OPT_G1_WIDE 7        /* int8 GEMM 1 with 128 rows per wave (gemm1_i8w_kernel: half the R-image traffic): 0 never,
+                                      1 (default) up to three tiles and >= 196 608 samples, 2 whenever the registers allow (<= 4)  */
 int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t value);
 
 /* name + average device time (ms, from hipEvents on the launch stream) of the kernels of the last

@@ -150,7 +150,7 @@ struct pyrhe_engine {
     }
     size_t total_bytes = 0;
     // launch-shape knobs (pyrhe_engine_set_option); every value computes the same results
-    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0;
+    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1;
     // kernels of the last sketch call (pyrhe_engine_info 6..8)
     int last_g1 = 0, last_g2 = 0, last_flow = 0;
 #ifdef PYRHE_DIAG
@@ -495,10 +495,16 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         // WAVES of gemm1_i8_kernel: a third of the R traffic at 12) and are slower -- 31.7 / 28.9 ms per pass against 27.6 at
         // the headline shape: the barrier of a 12-wave workgroup costs 32 % of its waves' time.
         constexpr int g1_waves = 4;
-        const int gx = (n + 64 * g1_waves - 1) / (64 * g1_waves);
+        // "wide" kernel (gemm1_i8w_kernel): 128 rows per wave, 512 per workgroup, half the R traffic, two waves per SIMD
+        // Measured (round 2): three tiles at N = 500k 25.3 vs 27.6 ms per pass; four tiles (236 registers) 37.6 vs 31.7; N = 50k
+        // 1.70 vs 1.65 -- so: up to three tiles and cohorts whose sample range alone gives every workgroup a long loop
+        // (opt_g1_wide: 0 never, 1 by that rule, 2 whenever the registers allow)
+        const bool wide = e->i8 && gv == 0 && ((e->opt_g1_wide == 1 && e->nt8 <= 3 && e->n_pad >= 192 * 1024) ||
+                                               (e->opt_g1_wide == 2 && e->nt8 <= 4));
+        const int gx = wide ? (n + 511) / 512 : (n + 64 * g1_waves - 1) / (64 * g1_waves);
         const int g1_ch = (e->i8 && e->nt8 > 3) ? 1 : 2;  // 256-sample chunks per step (see gemm1_i8_kernel)
         const int n_steps = n_chunks / g1_ch;             // pitch is a multiple of 256 B = 4 chunks
-        const int g1_wgs = std::max(1, e->opt_g1_wgs * 4 / g1_waves);     // target workgroups per launch (the knob counts 4-wave workgroups)
+        const int g1_wgs = std::max(1, (wide ? e->opt_g1_wgs * 2 / 3 : e->opt_g1_wgs) * 4 / g1_waves);   // target workgroups per launch (wide: 2 per CU instead of 3)
         int splits = (g1_wgs + gx - 1) / gx;
         splits = std::max(1, std::min(splits, n_steps / 4 > 0 ? n_steps / 4 : 1));
         int cps = (n_steps + splits - 1) / splits;        // steps per split, even (n_steps is even)
@@ -515,12 +521,14 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         g1_diag = e->diag_g1_no_barrier;                    // WRONG results: bit 0 no step barrier, bit 1 no wait for the R image
         if (e->diag_g1_stats && gv != 2) { g1_diag |= 4; Pbuf2 = reinterpret_cast<float*>(e->diag_g1_stats); }   // bit 2: phase cycle account
 #endif
-        e->last_g1 = e->i8 ? 100 + e->nt8 : e->ntl;
+        e->last_g1 = e->i8 ? (wide ? 200 : 100) + e->nt8 : e->ntl;
         if (e->i8) {
             const size_t lds = (size_t)2 * g1_ch * 4 * e->nt8 * 1024;
 #define G1I(NT_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag); \
                                   else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag); } while (0)
-#define G1J(NT_) do { if (gv == 0) { if (fill) G1I(NT_, true, 0); else G1I(NT_, false, 0); } \
+#define G1X(NT_, MISS_) do { if (e->vc) gemm1_i8w_kernel<NT_, MISS_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, sm); \
+                             else gemm1_i8w_kernel<NT_, MISS_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, sm); } while (0)
+#define G1J(NT_) do { if (wide) { if (fill) G1X(NT_, true); else G1X(NT_, false); break; } if (gv == 0) { if (fill) G1I(NT_, true, 0); else G1I(NT_, false, 0); } \
                       else if (gv == 1) { if (fill) G1I(NT_, true, 1); else G1I(NT_, false, 1); } \
                       else { if (fill) G1I(NT_, true, 2); else G1I(NT_, false, 2); } } while (0)
             switch (e->nt8) {
@@ -532,6 +540,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 default: G1J(6); break;
             }
 #undef G1J
+#undef G1X
 #undef G1I
         } else {
 #define G1(NTL_, PARTS_, EX_, GV_) launch_gemm1<NTL_, PARTS_, EX_, GV_>(e, packed, rows, n, fill, n_steps, cps, splits, stream)
@@ -854,6 +863,9 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
             e->opt_g2_splits = (int)value; break;
         case PYRHE_OPT_DOTS_GENERIC: e->opt_dots_generic = value != 0; break;
         case PYRHE_OPT_G1_SPLIT_MAJOR: e->opt_g1_split_major = value != 0; break;
+        case PYRHE_OPT_G1_WIDE:
+            if (value < 0 || value > 2) return fail(PYRHE_EINVAL, "G1_WIDE takes 0 (never), 1 (automatic) or 2 (whenever possible)");
+            e->opt_g1_wide = (int)value; break;
 #ifdef PYRHE_DIAG
         case 100: e->diag_g1_plain_store = value != 0; break;
         case 101: e->diag_g1_no_barrier = (int)value; break;

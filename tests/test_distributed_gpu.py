@@ -44,6 +44,23 @@ def test_bench_two_ranks_equal_one_rank(extra):
     assert np.allclose(a["config"]["sigma_se"], b["config"]["sigma_se"], rtol=1e-7)
 
 
+def test_bench_four_ranks_uneven_shards_equal_one_rank():
+    """Four ranks on one GPU (gloo), jn = 10: shards of 3, 3, 3, 1 blocks -- the driver's launch line with an uneven split."""
+    env = dict(os.environ, PYRHE_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    args = ["--n-indv", "12000", "--n-snp", "10000", "--jn", "10", "--steps", "1", "--warmup", "0", "--verify", "--no-cpu-baseline",
+            "--no-alt", "--n-bin", "2", "--n-cov", "3"]
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + args, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    four = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                           "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "4"] + args, cwd=REPO, env=env,
+                          capture_output=True, text=True, timeout=900)
+    assert four.returncode == 0, four.stderr[-2000:]
+    a, b = _last_json(one.stdout), _last_json(four.stdout)
+    assert b["n_gpus"] == 4
+    assert np.allclose(a["config"]["sigma_total"], b["config"]["sigma_total"], rtol=1e-9)
+    assert np.allclose(a["config"]["sigma_se"], b["config"]["sigma_se"], rtol=1e-7)
+
+
 def test_two_ranks_without_a_seed_agree(tmp_path):
     """seed=None (run_rhe.py's default) under a multi-rank launch: rank 0's clock-derived seed is broadcast, so every rank
     draws the same probe vectors and generated annotation (written once, by rank 0); both ranks report the same estimates."""

@@ -1,6 +1,7 @@
 """Oracle parity of the EXACT kernels and flows the headline number comes from, at the sizes where the engine selects them.
 
-bench.py's `value` is measured on ``gemm1_i8_kernel<3, .., VC>`` + ``gemm2_i8p_kernel<1>`` in the segmented flow (several
+bench.py's `value` is measured on ``gemm1_i8w_kernel<3, .., VC>`` (128 rows per wave; cohorts of >= 196 608 samples, else
+``gemm1_i8_kernel<3>``) + ``gemm2_i8p_kernel<1>`` in the segmented flow (several
 jackknife blocks per engine call), value-coded genotypes from the device generator, k = 10, one bin.  Those instantiations
 only engage for large cohorts / batched calls, so the small golden fixtures never reach them.  Here the same runner
 configuration as bench.py is driven at N = 500 000 (BASELINE config 3's cohort size), N = 50 000 (config 2) and N = 200 000
@@ -133,6 +134,15 @@ def _check(p, runner, engs, want_path, blocks_per_call):
 def test_headline_kernels_at_n500k_vs_oracle():
     """BASELINE config 3's cohort size: three 200-SNP blocks in ONE engine call (bench.py batches three 10 000-SNP blocks)."""
     p, runner, engs = _setup(500_000, 600, 3, 10)
+    _check(p, runner, engs, {"gemm1": 203, "gemm2": 11, "segmented": True}, blocks_per_call=3)       # 203: gemm1_i8w_kernel<3>
+
+
+def test_headline_kernels_at_n500k_narrow_gemm1_vs_oracle():
+    """The 64-rows-per-wave GEMM 1 (`g1_wide = 0`; what cohorts below 196 608 samples and four or more tiles run) at the same
+    size: both int8 GEMM 1 kernels are held to the oracle at N = 500 000."""
+    p, runner, engs = _setup(500_000, 600, 3, 10, row0=1000)
+    for e_ in engs:
+        e_.set_option("g1_wide", 0)
     _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3)
 
 
