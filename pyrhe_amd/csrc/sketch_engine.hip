@@ -504,7 +504,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         const int gx = wide ? (n + 511) / 512 : (n + 64 * g1_waves - 1) / (64 * g1_waves);
         const int g1_ch = (e->i8 && e->nt8 > 3) ? 1 : 2;  // 256-sample chunks per step (see gemm1_i8_kernel)
         const int n_steps = n_chunks / g1_ch;             // pitch is a multiple of 256 B = 4 chunks
-        const int g1_wgs = std::max(1, (wide ? e->opt_g1_wgs * 2 / 3 : e->opt_g1_wgs) * 4 / g1_waves);   // target workgroups per launch (wide: 2 per CU instead of 3)
+        const int g1_wgs = std::max(1, e->opt_g1_wgs * 4 / g1_waves);     // target workgroups per launch: 2 rounds of 3 per CU, or (wide: 2 per CU) 3 rounds -- measured 1024 / 1536 / 3072 wide workgroups: 25.3 / 24.5 / 26.5 ms
         int splits = (g1_wgs + gx - 1) / gx;
         splits = std::max(1, std::min(splits, n_steps / 4 > 0 ? n_steps / 4 : 1));
         int cps = (n_steps + splits - 1) / splits;        // steps per split, even (n_steps is even)
