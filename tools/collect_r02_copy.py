@@ -34,10 +34,12 @@ traffic = {"_comment": "HBM bytes per algorithmic byte of the two headline kerne
                        "launches of the PMC run (MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide streaming read on gfx950), "
                        "divided by the packed genotype bytes those launches covered; separate --pmc runs, profiles/r02_pmc_summary.txt",
            "commit": commit, "n_indv": N, "n_snp": SNPS, "jn": 10, "block_snps": 10000, "kernels": {}}
-for key, name in {"gemm1_i8_kernel": "void gemm1_i8_kernel<3, false, 0, true>", "gemm2_i8p_kernel": "void gemm2_i8p_kernel<1, false, true"}.items():
+for key, names in {"gemm1_i8_kernel": ["void gemm1_i8w_kernel<3, false, true", "void gemm1_i8_kernel<3, false, 0, true"],
+                   "gemm2_i8p_kernel": ["void gemm2_i8p_kernel<1, false, true"]}.items():
+    name = next(n for n in names if n in txt)          # the headline's GEMM 1 is gemm1_i8w_kernel since round 2
     nf, f = grab("pmc_fetch", name, "FETCH_SIZE")
     nw, w = grab("pmc_write", name, "WRITE_SIZE")
-    traffic["kernels"][key] = {"launches": nf, "fetch_size_mean": f, "write_size_mean": w,
+    traffic["kernels"][key] = {"kernel": name.replace("void ", "") + ">", "launches": nf, "fetch_size_mean": f, "write_size_mean": w,
                                "bytes_per_algorithmic_byte": round((2 * f * 1024 * nf + w * 1024 * nw) / alg, 4)}
 json.dump(traffic, open(f"{dst}/r02_traffic.json", "w"), indent=2)
 

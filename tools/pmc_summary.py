@@ -6,7 +6,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            k = row["Kernel_Name"].split("(")[0][:40]
+            k = row["Kernel_Name"].split("(")[0][:48]
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in sorted(agg.items()):
     if not any(x in k for x in ("gemm1", "gemm2", "mid")):
