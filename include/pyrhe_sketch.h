@@ -248,7 +248,8 @@ int pyrhe_synth_genotypes(uint8_t* packed, int64_t n_rows, int64_t pitch, int64_
  *   6 GEMM 1: 100 + tiles for gemm1_i8_kernel<tiles>, 200 + tiles for gemm1_i8w_kernel<tiles>, tiles for gemm1_kernel<tiles>
  *             (fp16), 0 before any call
  *   7 GEMM 2: 11 / 12 gemm2_i8p_kernel<NG = 1 / 2>, 1 gemm2_kernel (fp16 hi+lo or single), 0 none (no sketch columns)
- *   8 flow  : 1 segmented (one GEMM 1 over the concatenated lists, GEMM 2 by segment), 0 one kernel triple per list */
+ *   8 flow  : 1 segmented (one GEMM 1 over the concatenated lists, GEMM 2 by segment), 0 one kernel triple per list
+ *   9 merge : segments per workgroup of the last gemm2_i8p_kernel launch (> 1: short lists shared workgroups, PYRHE_OPT_G2_MERGE) */
 int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
 
 /*
@@ -264,6 +265,8 @@ int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
                                       share rows); default 0                                                        */
 #define PYRHE_OPT_G1_WIDE 7        /* int8 GEMM 1 with 128 rows per wave (gemm1_i8w_kernel: half the R-image traffic): 0 never,
                                       1 (default) up to three tiles and >= 196 608 samples, 2 whenever the registers allow (<= 4)  */
+#define PYRHE_OPT_G2_MERGE 8       /* packed int8 GEMM 2: consecutive short segments (bins of a block) share a workgroup while the
+                                      launch keeps this many workgroups; 0 = one segment per workgroup; default 1536             */
 int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t value);
 
 /* name + average device time (ms, from hipEvents on the launch stream) of the kernels of the last

@@ -150,9 +150,9 @@ struct pyrhe_engine {
     }
     size_t total_bytes = 0;
     // launch-shape knobs (pyrhe_engine_set_option); every value computes the same results
-    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1;
+    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536;
     // kernels of the last sketch call (pyrhe_engine_info 6..8)
-    int last_g1 = 0, last_g2 = 0, last_flow = 0;
+    int last_g1 = 0, last_g2 = 0, last_flow = 0, last_g2_merged = 0;
 #ifdef PYRHE_DIAG
     int diag_g1_plain_store = 0, diag_g1_no_barrier = 0;
     long long* diag_g1_stats = nullptr;   // device uint64[6]: cycles per loop phase + waves, summed over the launches    // diagnostic build only (tools/): never compiled into libpyrhe_sketch.so
@@ -160,6 +160,13 @@ struct pyrhe_engine {
 };
 
 static constexpr int kMaxTiles = 2;  // 32 logical columns
+// Packed int8 GEMM 2: dynamic LDS of a workgroup = the row list of its segment group (128 B per 32-entry K block), the
+// per-segment epilogue parameters (correction + 1 / scale of kSegCols columns) and the keep mask of its <= 1024 samples;
+// 64 KB at most, so the longest segment is 472 K blocks = 15 104 entries.
+static constexpr int kG2pSegCap = 472 * 32;
+static inline size_t g2p_lds(int kb32, int nseg) {
+    return (size_t)kb32 * 128 + (size_t)nseg * 2 * kSegCols * sizeof(float) + 1024 * sizeof(float);
+}
 // Two-stream overlap of GEMM 1 (next sub-block) with GEMM 2 (current): measured +3.5 % at N=500k (the two kernels
 // mostly time-share the CUs), at the price of per-kernel timings that include the contention.  Off by default;
 // pyrhe_engine_set_pipeline(e, 1) turns it on.
@@ -236,8 +243,8 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     const size_t oWtmp = carve(S * ncolmax * sizeof(float));
     const size_t oWscale = carve((size_t)kMaxSeg * kSegCols * sizeof(float));
     // every segment pads its tail to a 32-entry K block (64 for the int8 GEMM 2)
-    const size_t oWfrag = carve((S / 32 + kMaxSeg) * e->parts * kMaxTiles * 64 * sizeof(half8));
-    const size_t oRows = carve((S + 64 + 64 * kMaxSeg) * sizeof(int32_t));
+    const size_t oWfrag = carve((S / 32 + 4 * kMaxSeg) * e->parts * kMaxTiles * 64 * sizeof(half8));   // segments pad to 128 entries
+    const size_t oRows = carve((S + 128 + 128 * kMaxSeg) * sizeof(int32_t));
     e->ws_bytes = off;
     for (int i = 0; i < 2; ++i) {
         uint8_t* base = nullptr;
@@ -300,6 +307,7 @@ extern "C" int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what) {
         case 6: return e->last_g1;
         case 7: return e->last_g2;
         case 8: return e->last_flow;
+        case 9: return e->last_g2_merged;
         default: return -1;
     }
 }
@@ -454,6 +462,10 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     const bool g2p_off = e->opt_g2_packed == 0;
     const bool g2p_ok = !g2p_off && e->i8 && e->parts == 2 && e->n_sketch >= 1 && e->n_sketch <= 2 * kI8pCols && !dom;
     const int g2p_ng = e->n_sketch <= kI8pCols ? 1 : 2;        // column groups of 10 = pairs of A tiles
+    // Several short lists per call (the bins of a block): consecutive segments share a workgroup of the packed GEMM 2 as long
+    // as the launch keeps opt_g2_merge workgroups; such segments are padded to whole ring turns (128 entries), others to 64.
+    const int g2p_gx = (int)((e->n_pad + 1023) / 1024) * g2p_ng;
+    const bool g2p_merge = g2p_ok && e->opt_g2_merge > 0 && (int64_t)nbin * g2p_gx / e->opt_g2_merge >= 2;
     // RHE_DOM (per-list flow, three GEMM 2 launches per list, the third under the [g == 2] view): the packed kernel as a
     // one-segment launch, for cohorts whose sample range alone fills the chip; lists go in pieces of <= 16384 entries
     const bool g2p_dom = !g2p_off && e->i8 && e->parts == 2 && dom && e->n_sketch >= 1 && e->n_sketch <= kI8pCols &&
@@ -622,22 +634,49 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         ProfScope ps(e, sB2, 2);
         e->last_g2 = ((g2p_dom && segmode) || (g2p_ok && segmode && gv == 0)) ? (g2p_dom && segmode ? 11 : 10 + g2p_ng) : 1;
 #define G2(NTO_, PARTS_, IW_, EX_, GV_) launch_gemm2<NTO_, PARTS_, IW_, EX_, GV_>(e, packed, n_kb, kbps, splits, fill, outp, mode, partial, sB2, gtab)
+        // Packed int8 GEMM 2: consecutive segments share a workgroup (one row list in LDS, one pass of the load ring, an
+        // epilogue per segment) as long as the list fits the LDS budget (64 KB) and the grid keeps opt_g2_merge (1536 = three resident rounds) workgroups
+        // -- 8 bins x 1250 SNPs per block (20 ring steps per segment, a prologue + epilogue each) run as 12 segments per
+        // workgroup; long segments and small cohorts stay one per workgroup.
+        SegTab ptab = tab;
+        int ngrp = 0, grp_kb = 0, grp_seg = 1;
+        if (segmode) {
+            const int want = (g2p_merge && g2p_ok && gv == 0) ? std::max(1, (int)((int64_t)tab.nseg * g2p_gx / e->opt_g2_merge)) : 1;   // segments per group
+            for (int g = 0; g < tab.nseg;) {
+                ptab.grp0[ngrp++] = (unsigned char)g;
+                int kbs = tab.kb0[g + 1] - tab.kb0[g], n = 1;
+                while (g + n < tab.nseg && n < want && g2p_lds(kbs + tab.kb0[g + n + 1] - tab.kb0[g + n], n + 1) <= 65536) {
+                    kbs += tab.kb0[g + n + 1] - tab.kb0[g + n];
+                    ++n;
+                }
+                grp_kb = std::max(grp_kb, kbs);
+                grp_seg = std::max(grp_seg, n);
+                g += n;
+            }
+            ptab.grp0[ngrp] = (unsigned char)tab.nseg;
+            e->last_g2_merged = grp_seg;
+        }
         if (g2p_dom && segmode) {
-            dim3 grid((unsigned)((e->n_pad + 1023) / 1024), tab.nseg);
-            const size_t lds = (size_t)kbps * 128;
-#define L2D(MISS_, VC_, GV_) gemm2_i8p_kernel<1, MISS_, VC_, GV_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, tab)
+            dim3 grid((unsigned)((e->n_pad + 1023) / 1024), ngrp);
+            const size_t lds = g2p_lds(grp_kb, grp_seg);
+#define L2D(MISS_, VC_, GV_) gemm2_i8p_kernel<1, MISS_, VC_, GV_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, ptab)
 #define L2E(GV_) do { if (e->vc) { if (fill) L2D(true, true, GV_); else L2D(false, true, GV_); } \
                       else { if (fill) L2D(true, false, GV_); else L2D(false, false, GV_); } } while (0)
             if (gv == 0) L2E(0); else L2E(1);
 #undef L2E
 #undef L2D
         } else if (g2p_ok && segmode && gv == 0) {
-            dim3 grid((unsigned)((e->n_pad + 1023) / 1024 * g2p_ng), tab.nseg);       // NG = 2: a workgroup covers 512 samples
-            const size_t lds = (size_t)kbps * 128;
-#define L2P(NG_, MISS_, VC_) gemm2_i8p_kernel<NG_, MISS_, VC_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, tab)
+            dim3 grid((unsigned)((e->n_pad + 1023) / 1024 * g2p_ng), ngrp);           // NG = 2: a workgroup covers 512 samples
+            const size_t lds = g2p_lds(grp_kb, grp_seg);
+#define L2P(NG_, MISS_, VC_) gemm2_i8p_kernel<NG_, MISS_, VC_, 0, MERGE_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, ptab)
 #define L2Q(NG_) do { if (e->vc) { if (fill) L2P(NG_, true, true); else L2P(NG_, false, true); } \
                       else { if (fill) L2P(NG_, true, false); else L2P(NG_, false, false); } } while (0)
-            if (g2p_ng == 1) L2Q(1); else L2Q(2);
+#define MERGE_ true
+            if (grp_seg > 1) { if (g2p_ng == 1) L2Q(1); else L2Q(2); }
+#undef MERGE_
+#define MERGE_ false
+            if (grp_seg == 1) { if (g2p_ng == 1) L2Q(1); else L2Q(2); }
+#undef MERGE_
 #undef L2Q
 #undef L2P
         } else if (gv == 0) {
@@ -671,7 +710,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 if (out_norm && e->n_norm) HIPCHK(hipMemsetAsync(out_norm + (int64_t)b * e->n_norm, 0, e->n_norm * sizeof(double), stream));
             }
         const int64_t total = offsets_host[nbin];
-        const int64_t seg_cap = std::min<int64_t>(e->sub_snps, 512 * 32);   // GEMM 2 keeps a segment's row list in LDS
+        const int64_t seg_cap = std::min<int64_t>(e->sub_snps, kG2pSegCap);   // GEMM 2 keeps a segment's row list in LDS
         int b = 0;
         for (int64_t pos = 0; pos < total;) {
             SegTab tab = {};
@@ -687,7 +726,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 tab.acc[g] = (accumulate || touched[b]) ? 1 : 0;
                 touched[b] = 1;
                 n += take;
-                kb += g2p_ok ? 2 * ((take + 63) / 64) : (take + 31) / 32;     // the packed int8 GEMM 2 walks 64-entry K blocks
+                kb += g2p_ok ? (g2p_merge ? 4 * ((take + 127) / 128) : 2 * ((take + 63) / 64)) : (take + 31) / 32;   // the packed int8 GEMM 2 walks 64-entry K blocks
                 pos += take;
                 // A list cut here (longer than a segment may be, or than the chunk has room for) continues in the NEXT
                 // chunk: its pieces add into the same output slab and norm slot, and only launches are ordered -- the
@@ -740,7 +779,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             continue;
         }
         bool first = true;
-        const int64_t list_step = g2p_dom ? std::min<int64_t>(e->sub_snps, 512 * 32) : e->sub_snps;   // packed GEMM 2: row list in LDS
+        const int64_t list_step = g2p_dom ? std::min<int64_t>(e->sub_snps, kG2pSegCap) : e->sub_snps;   // packed GEMM 2: row list in LDS
         for (int64_t s0 = 0; s0 < n_b; s0 += list_step) {
             const int n = (int)std::min<int64_t>(list_step, n_b - s0);
             const int32_t* rows = entries + offsets_host[b] + s0;
@@ -866,6 +905,9 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
         case PYRHE_OPT_G1_WIDE:
             if (value < 0 || value > 2) return fail(PYRHE_EINVAL, "G1_WIDE takes 0 (never), 1 (automatic) or 2 (whenever possible)");
             e->opt_g1_wide = (int)value; break;
+        case PYRHE_OPT_G2_MERGE:
+            if (value < 0 || value > (1 << 20)) return fail(PYRHE_EINVAL, "G2_MERGE %lld outside 0..2^20", (long long)value);
+            e->opt_g2_merge = (int)value; break;
 #ifdef PYRHE_DIAG
         case 100: e->diag_g1_plain_store = value != 0; break;
         case 101: e->diag_g1_no_barrier = (int)value; break;

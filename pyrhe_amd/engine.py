@@ -155,7 +155,7 @@ def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28) -
 
 CODINGS = {"plink": 0, "value": 1}
 # PYRHE_OPT_* of include/pyrhe_sketch.h: launch-shape knobs, every value computes the same results
-OPTIONS = {"g1_workgroups": 1, "g2_packed": 2, "g2_iw": 3, "g2_splits": 4, "dots_generic": 5, "g1_split_major": 6, "g1_wide": 7,
+OPTIONS = {"g1_workgroups": 1, "g2_packed": 2, "g2_iw": 3, "g2_splits": 4, "dots_generic": 5, "g1_split_major": 6, "g1_wide": 7, "g2_merge": 8,
            "diag_g1_plain_store": 100, "diag_g1_no_barrier": 101, "diag_g1_stats": 102}     # 100+: only in the diagnostic build (PYRHE_LIB=...libpyrhe_sketch_diag.so), wrong results
 
 
@@ -348,9 +348,10 @@ class SketchEngine:
     def last_path(self) -> dict:
         """Which kernels the last sketch call launched (``pyrhe_engine_info`` 6..8): ``gemm1`` = 100 + tiles for the int8
         kernel / tiles for the fp16 kernel, ``gemm2`` = 11 / 12 packed int8 kernel with one / two column groups, 1 fp16
-        kernel, 0 none; ``segmented`` = one GEMM 1 over all lists of the call."""
-        g1, g2, fl = (int(self.lib.pyrhe_engine_info(self._h, w)) for w in (6, 7, 8))
-        return {"gemm1": g1, "gemm2": g2, "segmented": bool(fl)}
+        kernel, 0 none; ``segmented`` = one GEMM 1 over all lists of the call; ``g2_merged`` = segments per workgroup of the
+        last packed GEMM 2 launch (> 1: short lists shared workgroups, ``g2_merge`` option)."""
+        g1, g2, fl, mg = (int(self.lib.pyrhe_engine_info(self._h, w)) for w in (6, 7, 8, 9))
+        return {"gemm1": g1, "gemm2": g2, "segmented": bool(fl), "g2_merged": mg}
 
     def set_async(self, enable: bool):
         """Defer the per-call join: consecutive blocks then overlap (GEMM 1 of block j+1 beside GEMM 2 of block j)."""

@@ -523,3 +523,51 @@ def test_pipelined_streams_equal_serial(dev):
         eng.close()
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("k,with_fill,coding", [(10, False, "value"), (20, False, "value"), (20, True, "plink"), (7, True, "value")])
+def test_merged_segments_equal_one_segment_per_workgroup(dev, k, with_fill, coding):
+    """PYRHE_OPT_G2_MERGE: the packed int8 GEMM 2 lets consecutive short lists (the bins of a block) share a workgroup -- one
+    row list in LDS, one pass of the load ring, an epilogue per list inside the K loop, lists padded to whole ring turns.
+    Same bits as one list per workgroup (exact int32 accumulation, same float32 epilogue), for overwrite and accumulate calls,
+    with and without missing calls, 10- and 20-column kernels; info code 9 says whether lists really shared workgroups."""
+    from pyrhe_amd import engine
+    n, m = 5000, 9000
+    rng = np.random.default_rng(100 + k)
+    packed = engine.synth_genotypes(m, n, 17, 0, dev)
+    fill = None
+    if with_fill:
+        rows = torch.as_tensor(rng.choice(m, 300, replace=False), device=dev)
+        packed[rows, 11] = (packed[rows, 11] & 0xCF) | 0x10         # missing call (01) in the third crumb of byte 11
+        fill = torch.zeros(m, dtype=torch.float32, device=dev)
+        fill[rows] = torch.as_tensor(rng.integers(0, 3, 300), dtype=torch.float32, device=dev)
+    if coding == "value":
+        packed = engine.recode_rows(packed, "value")
+    sizes = (1250, 1250, 63, 1, 129, 640, 0, 2000, 1251, 64, 128, 700)            # odd, tiny, empty, ring-turn-sized lists
+    lists = [np.sort(rng.choice(m, sz, replace=False)).astype(np.int32) for sz in sizes]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+    entries = torch.from_numpy(np.concatenate(lists)).to(dev)
+    res, merged = [], []
+    for merge in (0, 2):                                            # 0: never; 2 workgroups per launch are enough to merge
+        eng = engine.SketchEngine(n, n, max_entries=m, precision="i8x3", device=dev)
+        eng.set_coding(coding)
+        eng.set_option("g2_merge", merge)
+        keep = eng.keep_vector([])
+        g = torch.Generator().manual_seed(3)
+        Z = torch.zeros((k, eng.n_pad), device=dev)
+        Z[:, :n] = torch.randn((k, n), generator=g).to(dev)
+        y = torch.zeros((1, eng.n_pad), device=dev)
+        y[:, :n] = torch.randn((1, n), generator=g).to(dev)
+        eng.set_rhs(Z, y, keep)
+        sk, nm, _ = eng.sketch_block(packed, entries, offs, fill=fill)
+        path = eng.last_path()
+        assert path["gemm2"] == (11 if k <= 10 else 12) and path["segmented"]
+        merged.append(path["g2_merged"])
+        sk2, nm2, _ = eng.sketch_block(packed, entries, offs, fill=fill, out_sketch=sk.clone(), out_norm=nm.clone(), accumulate=True)
+        torch.cuda.synchronize()
+        res.append([t.clone() for t in (sk, nm, sk2, nm2)])
+        eng.close()
+    assert merged[0] == 1 and merged[1] > 1
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert torch.count_nonzero(res[0][0][6]).item() == 0             # the empty list's slab

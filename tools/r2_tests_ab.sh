@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}" && mkdir -p gpurun_out/r2 && O=gpurun_out/r2
+timeout -k 10 900 python -m pytest tests -m gpu -q --maxfail=25 > $O/tests_check.log 2>&1
+rc=$?; echo "pytest rc $rc"; grep -E "passed|failed|^FAILED|^E  " $O/tests_check.log | cut -c1-300 | tail -n 30
+if [ $rc -ge 124 ]; then exit $rc; fi
+bash tools/r2_ab.sh pyrhe_amd/csrc/libpyrhe_sketch_old.so -
