@@ -161,11 +161,13 @@ struct pyrhe_engine {
 
 static constexpr int kMaxTiles = 2;  // 32 logical columns
 // Packed int8 GEMM 2: dynamic LDS of a workgroup = the row list of its segment group (128 B per 32-entry K block), the
-// per-segment epilogue parameters (correction + 1 / scale of kSegCols columns) and the keep mask of its <= 1024 samples;
-// 64 KB at most, so the longest segment is 472 K blocks = 15 104 entries.
+// per-segment epilogue parameters (correction + 1 / scale of kSegCols columns), the keep mask of its <= 1024 samples and the
+// epilogue's staging buffer (which lies over the row list when the group is one segment); 64 KB at most, so the longest
+// segment is 472 K blocks = 15 104 entries.
 static constexpr int kG2pSegCap = 472 * 32;
-static inline size_t g2p_lds(int kb32, int nseg) {
-    return (size_t)kb32 * 128 + (size_t)nseg * 2 * kSegCols * sizeof(float) + 1024 * sizeof(float);
+static inline size_t g2p_lds(int kb32, int nseg, int ng) {
+    const size_t rows = (size_t)kb32 * 128, stage = (size_t)g2p_stage_floats(ng) * sizeof(float);
+    return (nseg > 1 ? rows + stage : std::max(rows, stage)) + (size_t)nseg * 2 * kSegCols * sizeof(float) + 1024 * sizeof(float);
 }
 // Two-stream overlap of GEMM 1 (next sub-block) with GEMM 2 (current): measured +3.5 % at N=500k (the two kernels
 // mostly time-share the CUs), at the price of per-kernel timings that include the contention.  Off by default;
@@ -640,12 +642,13 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         // workgroup; long segments and small cohorts stay one per workgroup.
         SegTab ptab = tab;
         int ngrp = 0, grp_kb = 0, grp_seg = 1;
+        const int lds_ng = (g2p_ok && gv == 0) ? g2p_ng : 1;
         if (segmode) {
             const int want = (g2p_merge && g2p_ok && gv == 0) ? std::max(1, (int)((int64_t)tab.nseg * g2p_gx / e->opt_g2_merge)) : 1;   // segments per group
             for (int g = 0; g < tab.nseg;) {
                 ptab.grp0[ngrp++] = (unsigned char)g;
                 int kbs = tab.kb0[g + 1] - tab.kb0[g], n = 1;
-                while (g + n < tab.nseg && n < want && g2p_lds(kbs + tab.kb0[g + n + 1] - tab.kb0[g + n], n + 1) <= 65536) {
+                while (g + n < tab.nseg && n < want && g2p_lds(kbs + tab.kb0[g + n + 1] - tab.kb0[g + n], n + 1, lds_ng) <= 65536) {
                     kbs += tab.kb0[g + n + 1] - tab.kb0[g + n];
                     ++n;
                 }
@@ -658,7 +661,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         }
         if (g2p_dom && segmode) {
             dim3 grid((unsigned)((e->n_pad + 1023) / 1024), ngrp);
-            const size_t lds = g2p_lds(grp_kb, grp_seg);
+            const size_t lds = g2p_lds(grp_kb, grp_seg, lds_ng);
 #define L2D(MISS_, VC_, GV_) gemm2_i8p_kernel<1, MISS_, VC_, GV_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, ptab)
 #define L2E(GV_) do { if (e->vc) { if (fill) L2D(true, true, GV_); else L2D(false, true, GV_); } \
                       else { if (fill) L2D(true, false, GV_); else L2D(false, false, GV_); } } while (0)
@@ -667,7 +670,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
 #undef L2D
         } else if (g2p_ok && segmode && gv == 0) {
             dim3 grid((unsigned)((e->n_pad + 1023) / 1024 * g2p_ng), ngrp);           // NG = 2: a workgroup covers 512 samples
-            const size_t lds = g2p_lds(grp_kb, grp_seg);
+            const size_t lds = g2p_lds(grp_kb, grp_seg, lds_ng);
 #define L2P(NG_, MISS_, VC_) gemm2_i8p_kernel<NG_, MISS_, VC_, 0, MERGE_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, ptab)
 #define L2Q(NG_) do { if (e->vc) { if (fill) L2P(NG_, true, true); else L2P(NG_, false, true); } \
                       else { if (fill) L2P(NG_, true, false); else L2P(NG_, false, false); } } while (0)
