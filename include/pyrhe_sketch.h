@@ -267,6 +267,8 @@ int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
                                       1 (default) up to three tiles and >= 196 608 samples, 2 whenever the registers allow (<= 4)  */
 #define PYRHE_OPT_G2_MERGE 8       /* packed int8 GEMM 2: consecutive short segments (bins of a block) share a workgroup while the
                                       launch keeps this many workgroups; 0 = one segment per workgroup; default 1536             */
+#define PYRHE_OPT_G1_ZERO_ROWS 9   /* int8 GEMM 1: lanes of the last tile's unused digit rows fetch one shared zero
+                                      entry of the R image instead of their own zeros; default 1                               */
 int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t value);
 
 /* name + average device time (ms, from hipEvents on the launch stream) of the kernels of the last

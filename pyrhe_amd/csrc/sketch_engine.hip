@@ -150,7 +150,7 @@ struct pyrhe_engine {
     }
     size_t total_bytes = 0;
     // launch-shape knobs (pyrhe_engine_set_option); every value computes the same results
-    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536;
+    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1;
     // kernels of the last sketch call (pyrhe_engine_info 6..8)
     int last_g1 = 0, last_g2 = 0, last_flow = 0, last_g2_merged = 0;
 #ifdef PYRHE_DIAG
@@ -536,12 +536,13 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         if (e->diag_g1_stats && gv != 2) { g1_diag |= 4; Pbuf2 = reinterpret_cast<float*>(e->diag_g1_stats); }   // bit 2: phase cycle account
 #endif
         e->last_g1 = e->i8 ? (wide ? 200 : 100) + e->nt8 : e->ntl;
+        const int live_last = e->opt_g1_zero_rows ? 3 * e->n_user + 1 - 16 * (e->nt8 - 1) : 16;     // live digit rows of the last int8 tile
         if (e->i8) {
             const size_t lds = (size_t)2 * g1_ch * 4 * e->nt8 * 1024;
-#define G1I(NT_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag); \
-                                  else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag); } while (0)
-#define G1X(NT_, MISS_) do { if (e->vc) gemm1_i8w_kernel<NT_, MISS_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, sm); \
-                             else gemm1_i8w_kernel<NT_, MISS_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, sm); } while (0)
+#define G1I(NT_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag, live_last); \
+                                  else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag, live_last); } while (0)
+#define G1X(NT_, MISS_) do { if (e->vc) gemm1_i8w_kernel<NT_, MISS_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, sm, live_last); \
+                             else gemm1_i8w_kernel<NT_, MISS_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, sm, live_last); } while (0)
 #define G1J(NT_) do { if (wide) { if (fill) G1X(NT_, true); else G1X(NT_, false); break; } if (gv == 0) { if (fill) G1I(NT_, true, 0); else G1I(NT_, false, 0); } \
                       else if (gv == 1) { if (fill) G1I(NT_, true, 1); else G1I(NT_, false, 1); } \
                       else { if (fill) G1I(NT_, true, 2); else G1I(NT_, false, 2); } } while (0)
@@ -908,6 +909,7 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
         case PYRHE_OPT_G1_WIDE:
             if (value < 0 || value > 2) return fail(PYRHE_EINVAL, "G1_WIDE takes 0 (never), 1 (automatic) or 2 (whenever possible)");
             e->opt_g1_wide = (int)value; break;
+        case PYRHE_OPT_G1_ZERO_ROWS: e->opt_g1_zero_rows = value != 0; break;
         case PYRHE_OPT_G2_MERGE:
             if (value < 0 || value > (1 << 20)) return fail(PYRHE_EINVAL, "G2_MERGE %lld outside 0..2^20", (long long)value);
             e->opt_g2_merge = (int)value; break;
