@@ -269,6 +269,9 @@ int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
                                       launch keeps this many workgroups; 0 = one segment per workgroup; default 1536             */
 #define PYRHE_OPT_G1_ZERO_ROWS 9   /* int8 GEMM 1: lanes of the last tile's unused digit rows fetch one shared zero
                                       entry of the R image instead of their own zeros; default 1                               */
+#define PYRHE_OPT_LIST_SPAN 10     /* 1: the caller vouches that the rows of every entry list span < 2^32 bytes and < 2^24 rows; a
+                                      call may then address more than 2^32 bytes of rows (several blocks of a large cohort in one
+                                      launch) on the int8 path with <= 20 sketch columns (other paths still refuse); default 0 */
 int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t value);
 
 /* name + average device time (ms, from hipEvents on the launch stream) of the kernels of the last

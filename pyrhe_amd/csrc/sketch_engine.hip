@@ -150,7 +150,7 @@ struct pyrhe_engine {
     }
     size_t total_bytes = 0;
     // launch-shape knobs (pyrhe_engine_set_option); every value computes the same results
-    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1;
+    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1, opt_list_span = 0;
     // kernels of the last sketch call (pyrhe_engine_info 6..8)
     int last_g1 = 0, last_g2 = 0, last_flow = 0, last_g2_merged = 0;
 #ifdef PYRHE_DIAG
@@ -432,7 +432,8 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                         (long long)(offsets_host[b + 1] - offsets_host[b]), (long long)e->max_entries);
     }
     if (offsets_host[nbin] > 0 && !entries) return fail(PYRHE_EINVAL, "entries is NULL");
-    if (n_rows >= (1 << 24) || e->pitch >= (1 << 24) || (uint64_t)n_rows * (uint64_t)e->pitch >= (1ull << 32))
+    const bool wide_rows = n_rows >= (1 << 24) || (uint64_t)n_rows * (uint64_t)e->pitch >= (1ull << 32);
+    if (n_rows >= (1ll << 31) || e->pitch >= (1 << 24) || (wide_rows && !e->opt_list_span))
         return fail(PYRHE_EINVAL, "block of %lld rows x %lld bytes exceeds the 32-bit row offsets of one call; split it",
                     (long long)n_rows, (long long)e->pitch);
     const bool dom = out_dom != nullptr || norm_dom != nullptr;
@@ -705,6 +706,11 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     // small cohorts keep the per-list flow, whose GEMM 2 can split K over workgroups)
     const bool segflow = !dom && (nbin > 1 || (g2p_ok && e->n_pad >= 192 * 1024));
     e->last_flow = segflow ? 1 : 0;
+    // rows beyond the 32-bit offsets of one call: only the packed int8 GEMM 2 addresses a list relative to its lowest row
+    // (PYRHE_OPT_LIST_SPAN: the caller vouches for every list spanning < 2^32 bytes and < 2^24 rows)
+    if (wide_rows && !(segflow && g2p_ok))
+        return fail(PYRHE_EINVAL, "block of %lld rows x %lld bytes exceeds the 32-bit row offsets of one call on this kernel path; split it",
+                    (long long)n_rows, (long long)e->pitch);
     e->last_g2 = 0;
     if (segflow) {
         std::vector<char> touched(nbin, 0);
@@ -910,6 +916,7 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
             if (value < 0 || value > 2) return fail(PYRHE_EINVAL, "G1_WIDE takes 0 (never), 1 (automatic) or 2 (whenever possible)");
             e->opt_g1_wide = (int)value; break;
         case PYRHE_OPT_G1_ZERO_ROWS: e->opt_g1_zero_rows = value != 0; break;
+        case PYRHE_OPT_LIST_SPAN: e->opt_list_span = value != 0; break;
         case PYRHE_OPT_G2_MERGE:
             if (value < 0 || value > (1 << 20)) return fail(PYRHE_EINVAL, "G2_MERGE %lld outside 0..2^20", (long long)value);
             e->opt_g2_merge = (int)value; break;

@@ -221,6 +221,7 @@ class SketchRunner:
         self.pass2_impl = "hip"       # "torch": materialised cross-check path (tests)
         self.one_slot = False         # this trait group keeps ONE block slot and re-sketches in pass 2 (begin_trait decides)
         self.row_limit = None         # rows one engine call may address; None = from the engine's 32-bit byte offsets
+        self._span_ok = None          # see _lists_may_span_calls
         self._entries_cache = {}
         self._stats = None
         self._check_missing = True
@@ -364,11 +365,35 @@ class SketchRunner:
         cap = int(getattr(self.eng, "sub_snps", 0)) or self.plan.max_block
         by_entries = cap // max(self.plan.max_block, 1)
         by_bytes = self._row_limit() // max(self.plan.max_block, 1)
+        if by_bytes >= 1 and by_bytes < by_entries and self._lists_may_span_calls():
+            by_bytes = by_entries          # the call addresses every list relative to its own lowest row (PYRHE_OPT_LIST_SPAN)
         by_lists = MAX_SEGMENTS // max(self.plan.n_bin, 1)
         # (Choosing the batch so that GEMM 2's launch fills whole rounds of resident workgroups -- N = 50k: 10 blocks = 490
         # workgroups in one round of 512 instead of 13 = 637 in two -- was measured: GEMM 2 1.34 -> 1.21 ms per pass, GEMM 1
         # 1.66 -> 1.77 ms with two more launches: no gain; the largest batch stays.)
         return max(1, min(by_entries, by_bytes, by_lists))
+
+    def _lists_may_span_calls(self) -> bool:
+        """Whether one engine call may address more rows than its 32-bit byte offsets reach (N = 500k: more than three
+        10 000-SNP blocks): the int8 path with <= 20 sketch columns in the segmented flow addresses every entry list relative
+        to its own lowest row, if the caller vouches that no LIST spans more (here: every list lies inside its block, and a
+        block fits the limit).  GEMM 1 pays a fixed cost per launch -- 29.5 / 26.0 / 24.5 ms per pass at 1 / 2 / 3 blocks per
+        call at N = 500k -- so larger calls are worth having."""
+        if self._span_ok is None:
+            if not hasattr(self, "n_pass") or any(getattr(e_, "n_sketch", 0) + getattr(e_, "n_norm", 0) == 0
+                                                  for e_ in self.engs[:self.n_pass]):
+                return False               # right-hand sides not installed yet (begin_trait): decide later
+            ok = (not self.dom and self.row_limit is None and all(hasattr(e_, "set_option") for e_ in self.engs[:self.n_pass])
+                  and all(getattr(e_, "precision", "") == "i8x3" and 1 <= e_.n_sketch <= 20 for e_ in self.engs[:self.n_pass])
+                  and (self.plan.n_bin > 1 or self.n_pad >= 192 * 1024))
+            if ok:
+                from .engine import OPTIONS
+                ok = "list_span" in OPTIONS
+            if ok:
+                for e_ in self.engs[:self.n_pass]:
+                    e_.set_option("list_span", 1)
+            self._span_ok = bool(ok)
+        return self._span_ok
 
     def _row_limit(self) -> int:
         """Rows one engine call can address: its row byte offsets are 32-bit (rows * pitch < 2^32, rows < 2^24)."""

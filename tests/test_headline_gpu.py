@@ -216,3 +216,36 @@ def test_projector_kernel_vs_oracle_float32_chain():
         assert np.abs(got[r, :n] - ref32).max() <= 1e-5 * scale     # torch's float32 GEMV order over 20 000 samples: 2e-6 of noise
         assert np.abs(got[r, :n] - exact[r]).max() <= 1e-6 * scale
     eng.close()
+
+
+def test_calls_beyond_4gb_of_rows_equal_three_block_calls():
+    """PYRHE_OPT_LIST_SPAN: at N = 500k a call of more than 34 308 rows passes the 32-bit row offsets; the packed int8
+    GEMM 2 addresses every list relative to its own lowest row, so the runner batches by entries alone (GEMM 1 pays a fixed
+    cost per launch).  Four 10 000-SNP blocks (5 GB of rows) in ONE call against the same blocks at three per call:
+    the per-block sketches are the same bits (exact int32 accumulation, per-list float32 epilogue)."""
+    from pyrhe_amd import engine
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner
+    dev = torch.device("cuda", 0)
+    N, M, jn, k = 500_000, 40_000, 4, 10
+    outs = []
+    for limit in (None, 34_000):
+        eng = engine.SketchEngine(N, N, max_entries=65536, precision="i8x3", device=dev, sub_snps=65536)
+        geno = engine.synth_genotypes(M, N, 31, 0, dev)
+        geno = engine.recode_rows(geno, "value")
+        eng.set_coding("value")
+        plan = BlockPlan(np.ones((M, 1), dtype=np.int64), jn)
+        Z = np.random.default_rng(5).standard_normal((N, k)).astype(np.float32)
+        runner = SketchRunner([eng], geno, plan, (0, jn), n_orig=N, missing_indv=[], Z=Z, cov=None, seed=0, streaming=True)
+        runner.row_limit = limit
+        y = np.random.default_rng(6).standard_normal(N)
+        runner.begin_trait(y - y.mean(), check_missing=False)
+        assert runner._blocks_per_call() == (6 if limit is None else 3)
+        runner.pass1()
+        torch.cuda.synchronize()
+        assert eng.last_path()["gemm2"] == 11 and eng.last_path()["segmented"]
+        outs.append([t.clone() for t in runner.blocks_sk[0][:jn]] + [runner.blocks_nm[0][:jn].clone()])
+        eng.close()
+        del runner, geno
+        torch.cuda.empty_cache()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
