@@ -272,6 +272,8 @@ int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
 #define PYRHE_OPT_LIST_SPAN 10     /* 1: the caller vouches that the rows of every entry list span < 2^32 bytes and < 2^24 rows; a
                                       call may then address more than 2^32 bytes of rows (several blocks of a large cohort in one
                                       launch) on the int8 path with <= 20 sketch columns (other paths still refuse); default 0 */
+#define PYRHE_OPT_G1_FILL 11       /* int8 GEMM 1: among the sample-split counts near the G1_WORKGROUPS target take the one whose
+                                      workgroups fill whole rounds of the chip's resident slots best; 0 = the plain target; default 1 */
 int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t value);
 
 /* name + average device time (ms, from hipEvents on the launch stream) of the kernels of the last

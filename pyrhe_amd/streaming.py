@@ -105,10 +105,12 @@ MAX_SEGMENTS = 64               # kMaxSeg of the engine: (block, bin) lists one 
 
 
 def engine_capacity(plan: "BlockPlan") -> int:
-    """``max_entries`` / ``sub_snps`` to create the engines with: at least one block, and room (65 536 entries per kernel
-    chunk) to sketch several blocks in one call -- see SketchRunner.sketch_local_blocks.  Measured on MI355X
-    (16 384 -> 65 536): N=50k 71 -> 122 M SNPs/s, N=500k 15.3 -> 16.2 M; beyond that the gain flattens."""
-    return max(int(plan.max_block), int(os.environ.get("PYRHE_CAPACITY", "65536")))
+    """``max_entries`` / ``sub_snps`` to create the engines with: at least one block, and room (131 072 entries per kernel
+    chunk) to sketch several blocks in one call -- see SketchRunner.sketch_local_blocks.  Measured on MI355X: round 1
+    (16 384 -> 65 536) N=50k 71 -> 122 M SNPs/s, N=500k 15.3 -> 16.2 M; round 2, once a call may pass the 32-bit row
+    offsets (PYRHE_OPT_LIST_SPAN) and GEMM 1 picks its split count by how the workgroups fill the chip: 65 536 / 131 072 /
+    262 144 entries = 6 / 13 / 26 blocks per call at N=500k: 21.4 / 21.9 / 21.3 M SNPs/s, N=50k 144 / 162 / 165 M."""
+    return max(int(plan.max_block), int(os.environ.get("PYRHE_CAPACITY", "131072")))
 
 
 def plan_passes(k: int, n_groups: int, n_norm: int):
