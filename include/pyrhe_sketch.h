@@ -112,6 +112,9 @@ int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int32_t* role_
  * standardize_geno (:291-296) and the k GEMV pairs of _compute_XXz/_compute_XXUz/_compute_yXXy
  * (:403-417) as called from StreamingRHE.pre_compute_jackknife_bin(_pass_2)
  * (pyrhe/src/models/rhe/streaming_rhe.py:13-43).   Asynchronous on `stream`.
+ * Limits: n_rows * pitch < 2^32 and n_rows < 2^24 (32-bit row byte offsets; PYRHE_EINVAL beyond, "split it"), unless the
+ * caller set PYRHE_OPT_LIST_SPAN -- then only every single LIST must stay within that span and n_rows < 2^31 (several
+ * blocks of a large cohort in one call: the entry lists of consecutive jackknife blocks are just more bins of the call).
  */
 int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                               const int32_t* entries, const int64_t* offsets_host, int nbin,
