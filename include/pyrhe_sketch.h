@@ -267,7 +267,7 @@ int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
 #define PYRHE_OPT_G1_SPLIT_MAJOR 6 /* 1: GEMM 1 grid with the sample split as the fast index (co-resident workgroups
                                       share rows); default 0                                                        */
 #define PYRHE_OPT_G1_WIDE 7        /* int8 GEMM 1 with 128 rows per wave (gemm1_i8w_kernel: half the R-image traffic): 0 never,
-                                      1 (default) up to three tiles and >= 196 608 samples, 2 whenever the registers allow (<= 4)  */
+                                      1 (default) up to three tiles and >= 196 608 samples or enough rows per call to fill the chip, 2 whenever the registers allow (<= 4)  */
 #define PYRHE_OPT_G2_MERGE 8       /* packed int8 GEMM 2: consecutive short segments (bins of a block) share a workgroup while the
                                       launch keeps this many workgroups; 0 = one segment per workgroup; default 1536             */
 #define PYRHE_OPT_G1_ZERO_ROWS 9   /* int8 GEMM 1: lanes of the last tile's unused digit rows fetch one shared zero

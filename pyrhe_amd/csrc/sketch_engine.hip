@@ -518,7 +518,10 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         // Measured (round 2): three tiles at N = 500k 25.3 vs 27.6 ms per pass; four tiles (236 registers) 37.6 vs 31.7; N = 50k
         // 1.70 vs 1.65 -- so: up to three tiles and cohorts whose sample range alone gives every workgroup a long loop
         // (opt_g1_wide: 0 never, 1 by that rule, 2 whenever the registers allow)
-        const bool wide = e->i8 && gv == 0 && ((e->opt_g1_wide == 1 && e->nt8 <= 3 && e->n_pad >= 192 * 1024) ||
+        // Smaller cohorts take it too once a launch has rows enough to fill the chip with 512-row workgroups (N = 50k with 26
+        // blocks = 130 000 rows per call: 1.46 vs 1.56 ms per pass; with 3 000 rows per call the 64-row kernel stays).
+        const int64_t wide_par = (int64_t)((n + 511) / 512) * std::max(1, n_chunks / 8);      // row groups x largest split count
+        const bool wide = e->i8 && gv == 0 && ((e->opt_g1_wide == 1 && e->nt8 <= 3 && (e->n_pad >= 192 * 1024 || wide_par >= 1024)) ||
                                                (e->opt_g1_wide == 2 && e->nt8 <= 4));
         const int gx = wide ? (n + 511) / 512 : (n + 64 * g1_waves - 1) / (64 * g1_waves);
         const int g1_ch = (e->i8 && e->nt8 > 3) ? 1 : 2;  // 256-sample chunks per step (see gemm1_i8_kernel)

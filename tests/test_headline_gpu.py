@@ -152,6 +152,15 @@ def test_headline_kernels_at_n50k_vs_oracle():
     _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3)
 
 
+def test_headline_kernels_at_n50k_wide_gemm1_vs_oracle():
+    """The 128-rows-per-wave GEMM 1 at N = 50 000: bench.py's calls there (26 blocks = 130 000 rows) have rows enough for it
+    and take it by the automatic rule; three 1000-SNP blocks do not, so the test forces it (`g1_wide = 2`)."""
+    p, runner, engs = _setup(50_000, 3000, 3, 10, row0=29)
+    for e_ in engs:
+        e_.set_option("g1_wide", 2)
+    _check(p, runner, engs, {"gemm1": 203, "gemm2": 11, "segmented": True}, blocks_per_call=3)
+
+
 def test_c4_shape_8bins_covariates_at_n200k_vs_oracle():
     """BASELINE config 4's shape (8 bins + 10 covariates incl. the intercept): 21 right-hand columns = 64 packed digit rows =
     the four-tile int8 GEMM 1, 20 sketch columns = the two-column-group packed int8 GEMM 2; XXz, XXUz and yXXy per block."""
