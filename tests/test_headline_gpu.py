@@ -227,7 +227,8 @@ def test_projector_kernel_vs_oracle_float32_chain():
     eng.close()
 
 
-def test_calls_beyond_4gb_of_rows_equal_three_block_calls():
+@pytest.mark.parametrize("nbin,n_cov", [(1, 0), (8, 10)])
+def test_calls_beyond_4gb_of_rows_equal_three_block_calls(nbin, n_cov):
     """PYRHE_OPT_LIST_SPAN: at N = 500k a call of more than 34 308 rows passes the 32-bit row offsets; the packed int8
     GEMM 2 addresses every list relative to its own lowest row, so the runner batches by entries alone (GEMM 1 pays a fixed
     cost per launch).  Four 10 000-SNP blocks (5 GB of rows) in ONE call against the same blocks at three per call:
@@ -242,16 +243,24 @@ def test_calls_beyond_4gb_of_rows_equal_three_block_calls():
         geno = engine.synth_genotypes(M, N, 31, 0, dev)
         geno = engine.recode_rows(geno, "value")
         eng.set_coding("value")
-        plan = BlockPlan(np.ones((M, 1), dtype=np.int64), jn)
+        annot = np.zeros((M, nbin), dtype=np.int64)
+        annot[np.arange(M), np.random.default_rng(4).integers(0, nbin, M)] = 1
+        plan = BlockPlan(annot, jn)
         Z = np.random.default_rng(5).standard_normal((N, k)).astype(np.float32)
-        runner = SketchRunner([eng], geno, plan, (0, jn), n_orig=N, missing_indv=[], Z=Z, cov=None, seed=0, streaming=True)
+        cov = None
+        if n_cov:                                  # 8 bins + covariates: 20 sketch columns, merged segments, four-tile GEMM 1
+            cov = np.random.default_rng(7).standard_normal((N, n_cov))
+            cov[:, 0] = 1.0
+        runner = SketchRunner([eng], geno, plan, (0, jn), n_orig=N, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True,
+                              compat="fixed" if n_cov else "reference")
         runner.row_limit = limit
         y = np.random.default_rng(6).standard_normal(N)
         runner.begin_trait(y - y.mean(), check_missing=False)
         assert runner._blocks_per_call() == (6 if limit is None else 3)
         runner.pass1()
         torch.cuda.synchronize()
-        assert eng.last_path()["gemm2"] == 11 and eng.last_path()["segmented"]
+        path = eng.last_path()
+        assert path["gemm2"] == (12 if n_cov else 11) and path["segmented"] and (path["g2_merged"] > 1) == (nbin > 1)
         outs.append([t.clone() for t in runner.blocks_sk[0][:jn]] + [runner.blocks_nm[0][:jn].clone()])
         eng.close()
         del runner, geno
