@@ -571,3 +571,39 @@ def test_merged_segments_equal_one_segment_per_workgroup(dev, k, with_fill, codi
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert torch.count_nonzero(res[0][0][6]).item() == 0             # the empty list's slab
+
+
+def test_gemm1_launch_shape_options_do_not_change_a_bit(dev):
+    """The int8 GEMM 1 accumulates in exact int32 (integer atomics across the sample splits), so every launch shape gives the
+    same bits: workgroup target (G1_WORKGROUPS), round-filling choice of the split count (G1_FILL), 64- or 128-row kernel
+    (G1_WIDE), grid order (G1_SPLIT_MAJOR), shared zero rows of the last operand tile (G1_ZERO_ROWS)."""
+    from pyrhe_amd import engine
+    n, m, k = 40_000, 24_000, 10
+    rng = np.random.default_rng(77)
+    packed = engine.recode_rows(engine.synth_genotypes(m, n, 23, 0, dev), "value")
+    lists = [np.sort(rng.choice(m, sz, replace=False)).astype(np.int32) for sz in (9000, 5000, 7000)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+    entries = torch.from_numpy(np.concatenate(lists)).to(dev)
+    res, paths = [], set()
+    for opts in ({}, {"g1_fill": 0}, {"g1_workgroups": 300}, {"g1_workgroups": 5000}, {"g1_wide": 0}, {"g1_wide": 2},
+                 {"g1_wide": 2, "g1_workgroups": 700, "g1_split_major": 1}, {"g1_zero_rows": 0}):
+        eng = engine.SketchEngine(n, n, max_entries=m, precision="i8x3", device=dev, sub_snps=32768)
+        eng.set_coding("value")
+        for name, v in opts.items():
+            eng.set_option(name, v)
+        keep = eng.keep_vector([])
+        g = torch.Generator().manual_seed(12)
+        Z = torch.zeros((k, eng.n_pad), device=dev)
+        Z[:, :n] = torch.randn((k, n), generator=g).to(dev)
+        y = torch.zeros((1, eng.n_pad), device=dev)
+        y[:, :n] = torch.randn((1, n), generator=g).to(dev)
+        eng.set_rhs(Z, y, keep)
+        sk, nm, cs = eng.sketch_block(packed, entries, offs, want_colsum=True)
+        torch.cuda.synchronize()
+        paths.add(eng.last_path()["gemm1"])
+        res.append([t.clone() for t in (sk, nm, cs)])
+        eng.close()
+    assert paths == {103, 203}                                  # both int8 GEMM 1 kernels took part
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
