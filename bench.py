@@ -63,6 +63,9 @@ def parse_args():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="launch-shape knob of pyrhe_engine_set_option (pyrhe_amd.engine.OPTIONS), e.g. g1_workgroups=708; "
                          "every value computes the same results")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="pyrhe_engine_set_pipeline: GEMM 1 of call j+1 beside GEMM 2 of call j on two private streams (off by "
+                         "default: overlapped kernels blur the per-kernel durations the roofline object is built from)")
     ap.add_argument("--no-cross-check", action="store_true", help="skip the in-run i8x3 vs f16x2 comparison on three blocks")
     return ap.parse_args()
 
@@ -172,6 +175,8 @@ def main():
         e_.set_coding(coding)
         for name, val in opts:
             e_.set_option(name, val)
+        if args.pipeline:
+            e_.set_pipeline(True)
         return e_
 
     engine = make_engine(args.precision)
