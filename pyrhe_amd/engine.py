@@ -244,6 +244,7 @@ class SketchEngine:
         self._h = h
         self.n_cu = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
         self.n_sketch = 0
+        self.options = {}             # knobs set through set_option (the library's defaults otherwise)
         self.n_norm = 0
         self._keep = None
         self._rhs = None
@@ -344,6 +345,7 @@ class SketchEngine:
     def set_option(self, name: str, value: int):
         """Launch-shape knob of ``pyrhe_engine_set_option`` (see ``OPTIONS``)."""
         _check(self.lib.pyrhe_engine_set_option(self._h, OPTIONS[name], int(value)), f"pyrhe_engine_set_option({name})")
+        self.options[name] = int(value)
 
     def last_path(self) -> dict:
         """Which kernels the last sketch call launched (``pyrhe_engine_info`` 6..8): ``gemm1`` = 100 + tiles for the int8

@@ -386,7 +386,8 @@ class SketchRunner:
                                                   for e_ in self.engs[:self.n_pass]):
                 return False               # right-hand sides not installed yet (begin_trait): decide later
             ok = (not self.dom and self.row_limit is None and all(hasattr(e_, "set_option") for e_ in self.engs[:self.n_pass])
-                  and all(getattr(e_, "precision", "") == "i8x3" and 1 <= e_.n_sketch <= 20 for e_ in self.engs[:self.n_pass])
+                  and all(getattr(e_, "precision", "") == "i8x3" and 1 <= e_.n_sketch <= 20 and
+                          getattr(e_, "options", {}).get("g2_packed", 1) for e_ in self.engs[:self.n_pass])
                   and (self.plan.n_bin > 1 or self.n_pad >= 192 * 1024))
             if ok:
                 from .engine import OPTIONS
