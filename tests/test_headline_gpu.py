@@ -227,8 +227,8 @@ def test_projector_kernel_vs_oracle_float32_chain():
     eng.close()
 
 
-@pytest.mark.parametrize("nbin,n_cov", [(1, 0), (8, 10)])
-def test_calls_beyond_4gb_of_rows_equal_three_block_calls(nbin, n_cov):
+@pytest.mark.parametrize("nbin,n_cov,with_missing", [(1, 0, False), (8, 10, False), (2, 0, True)])
+def test_calls_beyond_4gb_of_rows_equal_three_block_calls(nbin, n_cov, with_missing):
     """PYRHE_OPT_LIST_SPAN: at N = 500k a call of more than 34 308 rows passes the 32-bit row offsets; the packed int8
     GEMM 2 addresses every list relative to its own lowest row, so the runner batches by entries alone (GEMM 1 pays a fixed
     cost per launch).  Four 10 000-SNP blocks (5 GB of rows) in ONE call against the same blocks at three per call:
@@ -241,6 +241,9 @@ def test_calls_beyond_4gb_of_rows_equal_three_block_calls(nbin, n_cov):
     for limit in (None, 34_000):
         eng = engine.SketchEngine(N, N, max_entries=65536, precision="i8x3", device=dev, sub_snps=65536)
         geno = engine.synth_genotypes(M, N, 31, 0, dev)
+        if with_missing:                           # missing calls in every block: the kernels' fill path (row | fill << 24 lists)
+            rows_m = torch.as_tensor(np.random.default_rng(3).choice(M, 500, replace=False), device=dev)
+            geno[rows_m, 123] = (geno[rows_m, 123] & 0xF3) | 0x04
         geno = engine.recode_rows(geno, "value")
         eng.set_coding("value")
         annot = np.zeros((M, nbin), dtype=np.int64)
@@ -255,12 +258,13 @@ def test_calls_beyond_4gb_of_rows_equal_three_block_calls(nbin, n_cov):
                               compat="fixed" if n_cov else "reference")
         runner.row_limit = limit
         y = np.random.default_rng(6).standard_normal(N)
-        runner.begin_trait(y - y.mean(), check_missing=False)
+        runner.begin_trait(y - y.mean(), check_missing=with_missing)
         assert runner._blocks_per_call() == (6 if limit is None else 3)
         runner.pass1()
         torch.cuda.synchronize()
         path = eng.last_path()
-        assert path["gemm2"] == (12 if n_cov else 11) and path["segmented"] and (path["g2_merged"] > 1) == (nbin > 1)
+        assert path["gemm2"] == (12 if n_cov else 11) and path["segmented"]
+        assert (path["g2_merged"] > 1) == (nbin == 8)        # 5000-entry lists with 10 columns: two of them do not fit the LDS
         outs.append([t.clone() for t in runner.blocks_sk[0][:jn]] + [runner.blocks_nm[0][:jn].clone()])
         eng.close()
         del runner, geno
