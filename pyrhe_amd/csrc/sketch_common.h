@@ -136,8 +136,8 @@ struct SegTab {
     int kb0[kMaxSeg + 1];
     int bin[kMaxSeg];
     unsigned char acc[kMaxSeg];   // 1: add to the caller's outputs of that bin, 0: overwrite
-    // the packed int8 GEMM 2 only: workgroup row y of its grid walks segments grp0[y] .. grp0[y+1]-1 (filled in by the launch)
-    unsigned char grp0[kMaxSeg + 1];
+    // the packed int8 GEMM 2 only: workgroup row y of its grid walks segments grp0[y] .. grp1[y]-1 (filled in by the launch)
+    unsigned char grp0[kMaxSeg], grp1[kMaxSeg];
 };
 __device__ __forceinline__ int seg_of_entry(const SegTab& t, int e) {
     int g = 0;

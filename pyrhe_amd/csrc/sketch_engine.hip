@@ -667,46 +667,67 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         // epilogue per segment) as long as the list fits the LDS budget (64 KB) and the grid keeps opt_g2_merge (1536 = three resident rounds) workgroups
         // -- 8 bins x 1250 SNPs per block (20 ring steps per segment, a prologue + epilogue each) run as 12 segments per
         // workgroup; long segments and small cohorts stay one per workgroup.
-        SegTab ptab = tab;
-        int ngrp = 0, grp_kb = 0, grp_seg = 1;
+        // Groups of ONE segment and groups of several go to separate launches (plain / MERGE kernel): a long list alone may fill
+        // the LDS budget with its rows (the staging buffer of its one epilogue lies over them), a merged group needs rows and
+        // staging side by side.
+        SegTab ptab1 = tab, ptabm = tab;                      // single-segment groups / merged groups
+        int ngrp1 = 0, ngrpm = 0, segmax = 1;
+        size_t lds1 = 0, ldsm = 0;                               // dynamic LDS of the two launches: the largest group's need
         const int lds_ng = (g2p_ok && gv == 0) ? g2p_ng : 1;
         if (segmode) {
             const int want = (g2p_merge && g2p_ok && gv == 0) ? std::max(1, (int)((int64_t)tab.nseg * g2p_gx / e->opt_g2_merge)) : 1;   // segments per group
             for (int g = 0; g < tab.nseg;) {
-                ptab.grp0[ngrp++] = (unsigned char)g;
                 int kbs = tab.kb0[g + 1] - tab.kb0[g], n = 1;
                 while (g + n < tab.nseg && n < want && g2p_lds(kbs + tab.kb0[g + n + 1] - tab.kb0[g + n], n + 1, lds_ng) <= 65536) {
                     kbs += tab.kb0[g + n + 1] - tab.kb0[g + n];
                     ++n;
                 }
-                grp_kb = std::max(grp_kb, kbs);
-                grp_seg = std::max(grp_seg, n);
+                if (n == 1) {
+                    ptab1.grp0[ngrp1] = (unsigned char)g;
+                    ptab1.grp1[ngrp1++] = (unsigned char)(g + 1);
+                    lds1 = std::max(lds1, g2p_lds(kbs, 1, lds_ng));
+                } else {
+                    ptabm.grp0[ngrpm] = (unsigned char)g;
+                    ptabm.grp1[ngrpm++] = (unsigned char)(g + n);
+                    ldsm = std::max(ldsm, g2p_lds(kbs, n, lds_ng));
+                    segmax = std::max(segmax, n);
+                }
                 g += n;
             }
-            ptab.grp0[ngrp] = (unsigned char)tab.nseg;
-            e->last_g2_merged = grp_seg;
+            e->last_g2_merged = segmax;
         }
         if (g2p_dom && segmode) {
-            dim3 grid((unsigned)((e->n_pad + 1023) / 1024), ngrp);
-            const size_t lds = g2p_lds(grp_kb, grp_seg, lds_ng);
-#define L2D(MISS_, VC_, GV_) gemm2_i8p_kernel<1, MISS_, VC_, GV_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, ptab)
+            dim3 grid((unsigned)((e->n_pad + 1023) / 1024), ngrp1);      // per-list flow: one segment, never merged
+            const size_t lds = lds1;
+#define L2D(MISS_, VC_, GV_) gemm2_i8p_kernel<1, MISS_, VC_, GV_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, ptab1)
 #define L2E(GV_) do { if (e->vc) { if (fill) L2D(true, true, GV_); else L2D(false, true, GV_); } \
                       else { if (fill) L2D(true, false, GV_); else L2D(false, false, GV_); } } while (0)
             if (gv == 0) L2E(0); else L2E(1);
 #undef L2E
 #undef L2D
         } else if (g2p_ok && segmode && gv == 0) {
-            dim3 grid((unsigned)((e->n_pad + 1023) / 1024 * g2p_ng), ngrp);           // NG = 2: a workgroup covers 512 samples
-            const size_t lds = g2p_lds(grp_kb, grp_seg, lds_ng);
-#define L2P(NG_, MISS_, VC_) gemm2_i8p_kernel<NG_, MISS_, VC_, 0, MERGE_><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, ptab)
+            const unsigned gxp = (unsigned)((e->n_pad + 1023) / 1024 * g2p_ng);       // NG = 2: a workgroup covers 512 samples
+#define L2P(NG_, MISS_, VC_) gemm2_i8p_kernel<NG_, MISS_, VC_, 0, MERGE_><<<dim3(gxp, NGRP_), 256, LDS_, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, outp, PTAB_)
 #define L2Q(NG_) do { if (e->vc) { if (fill) L2P(NG_, true, true); else L2P(NG_, false, true); } \
                       else { if (fill) L2P(NG_, true, false); else L2P(NG_, false, false); } } while (0)
 #define MERGE_ true
-            if (grp_seg > 1) { if (g2p_ng == 1) L2Q(1); else L2Q(2); }
+#define NGRP_ ngrpm
+#define LDS_ ldsm
+#define PTAB_ ptabm
+            if (ngrpm) { if (g2p_ng == 1) L2Q(1); else L2Q(2); }
 #undef MERGE_
+#undef NGRP_
+#undef LDS_
+#undef PTAB_
 #define MERGE_ false
-            if (grp_seg == 1) { if (g2p_ng == 1) L2Q(1); else L2Q(2); }
+#define NGRP_ ngrp1
+#define LDS_ lds1
+#define PTAB_ ptab1
+            if (ngrp1) { if (g2p_ng == 1) L2Q(1); else L2Q(2); }
 #undef MERGE_
+#undef NGRP_
+#undef LDS_
+#undef PTAB_
 #undef L2Q
 #undef L2P
         } else if (gv == 0) {

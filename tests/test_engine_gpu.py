@@ -532,7 +532,7 @@ def test_merged_segments_equal_one_segment_per_workgroup(dev, k, with_fill, codi
     Same bits as one list per workgroup (exact int32 accumulation, same float32 epilogue), for overwrite and accumulate calls,
     with and without missing calls, 10- and 20-column kernels; info code 9 says whether lists really shared workgroups."""
     from pyrhe_amd import engine
-    n, m = 5000, 9000
+    n, m = 5000, 12000
     rng = np.random.default_rng(100 + k)
     packed = engine.synth_genotypes(m, n, 17, 0, dev)
     fill = None
@@ -543,7 +543,9 @@ def test_merged_segments_equal_one_segment_per_workgroup(dev, k, with_fill, codi
         fill[rows] = torch.as_tensor(rng.integers(0, 3, 300), dtype=torch.float32, device=dev)
     if coding == "value":
         packed = engine.recode_rows(packed, "value")
-    sizes = (1250, 1250, 63, 1, 129, 640, 0, 2000, 1251, 64, 128, 700)            # odd, tiny, empty, ring-turn-sized lists
+    # odd, tiny, empty, ring-turn-sized lists -- and one list long enough to need the whole LDS budget for its rows alone
+    # (it goes to the single-segment launch, the short ones share workgroups in the merged launch)
+    sizes = (1250, 1250, 63, 1, 129, 640, 0, 2000, 1251, 64, 128, 700, 8800, 300, 200)
     lists = [np.sort(rng.choice(m, sz, replace=False)).astype(np.int32) for sz in sizes]
     offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
     entries = torch.from_numpy(np.concatenate(lists)).to(dev)
