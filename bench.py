@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--pipeline", action="store_true",
                     help="pyrhe_engine_set_pipeline: GEMM 1 of call j+1 beside GEMM 2 of call j on two private streams (off by "
                          "default: overlapped kernels blur the per-kernel durations the roofline object is built from)")
+    ap.add_argument("--materialize-xxuz", action="store_true",
+                    help="covariates as the k sketch columns U Z (the reference's XXUz arrays) instead of c cross columns whose "
+                         "Gram matrix W^T X X^T W replaces them (SketchRunner.cross)")
     ap.add_argument("--no-cross-check", action="store_true", help="skip the in-run i8x3 vs f16x2 comparison on three blocks")
     return ap.parse_args()
 
@@ -209,7 +212,8 @@ def main():
     engines = [engine] + [make_engine(args.precision) for _ in range(n_eng - 1)]
     compat = "fixed" if (cov is not None or args.genie) else "reference"
     runner = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, env=env,
-                          genie_model=args.genie, seed=0, streaming=True, dom=args.dom, compat=compat)
+                          genie_model=args.genie, seed=0, streaming=True, dom=args.dom, compat=compat,
+                          materialize_xxuz=args.materialize_xxuz)
     runner.begin_trait(y, check_missing=check_missing)      # the generator itself emits no missing calls (contract of synth_kernel)
 
     def barrier():
@@ -281,7 +285,7 @@ def main():
     # matrix-core work of the dominant kernel as issued (16-column tiles, all limbs / parts), beside the byte roofline:
     # (the fp16 GEMM 2 is bound by instruction issue; the packed int8 GEMM 2 and GEMM 1 by HBM)
     n_pad = engine.n_pad
-    tiles_in = (engine.n_sketch + engine.n_norm + 1 + 15) // 16              # + the ones column
+    tiles_in = (engine.n_sketch + engine.n_norm + engine.n_cross + 1 + 15) // 16              # + the ones column
     tiles_out = max(1, (engine.n_sketch + 15) // 16)
     rows_per_launch = local_snps / launches
     if dom == "gemm2_kernel" and g2_packed:
@@ -312,7 +316,8 @@ def main():
                                   + (f"StreamingGENIE {args.genie} (1 environment)" if args.genie else "StreamingRHE")
                                   + f" sketch pass, k={k} jn={jn}" + (f", {args.n_cov} covariates" if args.n_cov else ""),
                       "precision": args.precision, "coding": coding, "sub_snps": engine.sub_snps, "parallelism": f"blocks/{world}gpu",
-                      "options": dict(opts), "gen_seconds": round(t_gen, 2)},
+                      "options": dict(opts), "gen_seconds": round(t_gen, 2),
+                      "covariates_as": None if cov is None else ("cross columns (W^T X X^T W per block and bin)" if runner.cross else "U Z sketch columns")},
            "roofline": roofline}
 
     def extra(name, fn):
@@ -352,7 +357,8 @@ def main():
         for prec in (args.precision, "f16x2"):
             engs = [make_engine(prec, engine_capacity(sub)) for _ in range(n_eng)]
             rn = SketchRunner(engs, geno[s3 - r0:e3 - r0], sub, (0, nb3), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, env=env,
-                              genie_model=args.genie, seed=0, streaming=True, compat=compat, solo=True)
+                              genie_model=args.genie, seed=0, streaming=True, compat=compat, solo=True,
+                              materialize_xxuz=args.materialize_xxuz)
             sysm = rn.run_trait(y, check_missing=check_missing)
             sig = est.solve_all(sysm.T, sysm.q)
             res[prec] = (sig[-1], np.asarray(est.jackknife_se(sig[:-1], nb3)), engs[0].last_path())
@@ -418,7 +424,7 @@ def main():
             e_.close()
         engines = [make_engine("f16") for _ in range(n_eng)]
         rn = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, env=env,
-                          genie_model=args.genie, seed=0, streaming=True, compat=compat)
+                          genie_model=args.genie, seed=0, streaming=True, compat=compat, materialize_xxuz=args.materialize_xxuz)
         rn.begin_trait(y, check_missing=check_missing)
         rn.pass1()
         dt2 = timed_passes(rn)

@@ -62,7 +62,13 @@ extern "C" {
 #define PYRHE_COL_SKETCH 1  /* gets both contractions: out[:, col] = X (X^T r)   (a7/a9 in SURVEY 8a) */
 #define PYRHE_COL_NORM 2    /* gets sum_s (x_s^T r)^2                            (a8)                 */
 
-#define PYRHE_MAX_COLS 30   /* sketch + norm columns (a ones column is appended internally)    */
+#define PYRHE_COL_CROSS 3   /* gets the first contraction only; the engine returns, per bin, the Gram matrix of these
+                               columns' projections  sum_s (x_s^T r_i)(x_s^T r_j) = R_x^T X X^T R_x
+                               (pyrhe_engine_sketch_block_cross).  With the covariates W as cross columns that is all the
+                               normal equations need of XXUz = X X^T (U Z) (a9): it only enters through sum(XXUz * UXXz)
+                               (base.py:589-591), UXXz lies in span(W), and W^T X X^T (U Z) = (W^T X X^T W)(Q W^T Z).     */
+
+#define PYRHE_MAX_COLS 30   /* sketch + norm + cross columns (a ones column is appended internally) */
 
 typedef struct pyrhe_engine pyrhe_engine_t;
 
@@ -84,7 +90,7 @@ int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, int64_t max_e
 int pyrhe_engine_destroy(pyrhe_engine_t* e);
 
 /*
- * Install the right-hand columns.  R: device float [n_cols][n_pad]; role[c] in {SKETCH, NORM};
+ * Install the right-hand columns.  R: device float [n_cols][n_pad]; role[c] in {SKETCH, NORM, CROSS}, in that order;
  * keep: device float [n_pad] with 1 for retained samples and 0 for dropped / padding samples
  * (it becomes the internal "ones" column that yields the exact integer genotype sums).
  * Sketch columns must come first.  Builds fp16 MFMA-operand images, per-column power-of-two scales
@@ -113,8 +119,9 @@ int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int32_t* role_
  * (:403-417) as called from StreamingRHE.pre_compute_jackknife_bin(_pass_2)
  * (pyrhe/src/models/rhe/streaming_rhe.py:13-43).   Asynchronous on `stream`.
  * Limits: n_rows * pitch < 2^32 and n_rows < 2^24 (32-bit row byte offsets; PYRHE_EINVAL beyond, "split it"), unless the
- * caller set PYRHE_OPT_LIST_SPAN -- then only every single LIST must stay within that span and n_rows < 2^31 (several
- * blocks of a large cohort in one call: the entry lists of consecutive jackknife blocks are just more bins of the call).
+ * caller set PYRHE_OPT_LIST_SPAN = v -- then only every window of v consecutive lists (one jackknife block's bins) must stay
+ * within that span and n_rows < 2^31 (several blocks of a large cohort in one call: the entry lists of consecutive
+ * jackknife blocks are just more bins of the call).
  */
 int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                               const int32_t* entries, const int64_t* offsets_host, int nbin,
@@ -132,6 +139,23 @@ int pyrhe_engine_sketch_block_dom(pyrhe_engine_t* e, const uint8_t* packed, int6
                                   const int32_t* entries, const int64_t* offsets_host, int nbin,
                                   const float* fill, float* out_sketch, double* out_norm,
                                   float* out_sketch_dom, double* out_norm_dom, int accumulate, void* stream);
+
+/*
+ * As pyrhe_engine_sketch_block / _dom for an engine whose right-hand columns include PYRHE_COL_CROSS columns (they come
+ * last: sketch, norm, cross).  Additional outputs, same accumulate flag:
+ *   out_cross      device double [nbin][n_cross][n_cross] (+)= sum_{s in L_b} (x_s^T R_i)(x_s^T R_j) over the cross columns
+ *                  i, j (symmetric; the diagonal is what a norm column would give); ordered sums, bit-reproducible
+ *   out_cross_dom  the same under the dominance encoding; NULL unless out_sketch_dom / out_norm_dom are given
+ * out_sketch_dom, out_norm_dom, out_cross_dom all NULL: additive sketches only.  An engine may hold cross columns alone
+ * (no sketch columns: the call is one GEMM 1 + the small reductions, no second read of the genotypes).
+ * Replaces Base._compute_XXUz (pyrhe/src/base/base.py:410-412) as consumed by setup_lhs_rhs_jackknife (base.py:583-593):
+ * with R_x = W (the covariates), W^T XXUz_b = out_cross (Q W^T z_b).   Asynchronous on `stream`.
+ */
+int pyrhe_engine_sketch_block_cross(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
+                                    const int32_t* entries, const int64_t* offsets_host, int nbin,
+                                    const float* fill, float* out_sketch, double* out_norm, double* out_cross,
+                                    float* out_sketch_dom, double* out_norm_dom, double* out_cross_dom,
+                                    int accumulate, void* stream);
 
 /*
  * Pipelining across calls.  Internally the engine enqueues on private streams with two workspace sets (optionally
@@ -246,7 +270,7 @@ int pyrhe_decode_rows(const uint8_t* packed, int64_t n_rows, int64_t pitch, floa
 int pyrhe_synth_genotypes(uint8_t* packed, int64_t n_rows, int64_t pitch, int64_t n_samples,
                           uint64_t seed, int64_t row0, void* stream);
 
-/* engine introspection: 0 n_pad, 1 sub_snps, 2 n_tiles_in, 3 n_sketch, 4 n_norm, 5 workspace bytes;
+/* engine introspection: 0 n_pad, 1 sub_snps, 2 n_tiles_in, 3 n_sketch, 4 n_norm, 5 workspace bytes, 10 n_cross;
  * which kernels the LAST sketch call launched (so a parity test can assert the path it checked is the path it meant):
  *   6 GEMM 1: 100 + tiles for gemm1_i8_kernel<tiles>, 200 + tiles for gemm1_i8w_kernel<tiles>, tiles for gemm1_kernel<tiles>
  *             (fp16), 0 before any call
@@ -272,9 +296,12 @@ int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
                                       launch keeps this many workgroups; 0 = one segment per workgroup; default 1536             */
 #define PYRHE_OPT_G1_ZERO_ROWS 9   /* int8 GEMM 1: lanes of the last tile's unused digit rows fetch one shared zero
                                       entry of the R image instead of their own zeros; default 1                               */
-#define PYRHE_OPT_LIST_SPAN 10     /* 1: the caller vouches that the rows of every entry list span < 2^32 bytes and < 2^24 rows; a
-                                      call may then address more than 2^32 bytes of rows (several blocks of a large cohort in one
-                                      launch) on the int8 path with <= 20 sketch columns (other paths still refuse); default 0 */
+#define PYRHE_OPT_LIST_SPAN 10     /* v >= 1: the caller vouches that the rows of any v consecutive entry lists starting at a multiple
+                                      of v (v = bins per jackknife block: the lists of ONE block) together span < 2^32 bytes and
+                                      < 2^24 rows; a call may then address more than 2^32 bytes of rows (several blocks of a large
+                                      cohort in one launch) on the int8 path with <= 20 sketch columns (other paths still refuse).
+                                      The packed GEMM 2 addresses the lists that share a workgroup relative to their lowest row and
+                                      in such a call only lets lists of one such window share one.  Default 0 (refuse)            */
 #define PYRHE_OPT_G1_FILL 11       /* int8 GEMM 1: among the sample-split counts near the G1_WORKGROUPS target take the one whose
                                       workgroups fill whole rounds of the chip's resident slots best; 0 = the plain target; default 1 */
 int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t value);

@@ -83,7 +83,7 @@ struct pyrhe_engine {
     bool exact = false;   // exact (normal-number) genotype unpack instead of the 1-op subnormal unpack
     bool i8 = false;      // int8 digit kernels (precision i8x3: GEMM 1 always, GEMM 2 where the packed kernel applies)
     bool vc = false;      // the caller's packed buffers hold the 2-bit VALUE code (pyrhe_recode_rows), not PLINK codes
-    int n_sketch = 0, n_norm = 0, n_user = 0, ntl = 0, nto = 0, nt8 = 0;
+    int n_sketch = 0, n_norm = 0, n_cross = 0, n_user = 0, ntl = 0, nto = 0, nt8 = 0;
     bool rhs_set = false;
     // device buffers
     half8* rfrag = nullptr;
@@ -100,6 +100,7 @@ struct pyrhe_engine {
     uint32_t* wmax = nullptr;
     double* corr = nullptr;
     double* vsq = nullptr;        // [sub_snps][n_norm] squares of the norm columns, summed per segment by norm_reduce()
+    float* vcross = nullptr;      // [sub_snps][n_cross] V of the cross columns, Gram per segment by cross_reduce_kernel
     float* mu = nullptr;
     float* Wtmp = nullptr;
     float* wscale = nullptr;
@@ -113,13 +114,13 @@ struct pyrhe_engine {
     // sub-block g runs on stream B -- a DRAM-pattern-bound kernel beside an instruction-bound one.  The members
     // above alias the set in use (kernel arguments are captured by value at launch).
     struct WorkSet {
-        uint8_t* base; float* P; uint32_t* wmax; double* corr; double* vsq; float* mu; float* Wtmp; float* wscale;
+        uint8_t* base; float* P; uint32_t* wmax; double* corr; double* vsq; float* vcross; float* mu; float* Wtmp; float* wscale;
         half8* wfrag; int32_t* rows32;
     } sets[2];
     // dominance (RHE_DOM) extras, allocated on first use: one zeroed region (P2 | wmax2) + vsq2, W2, cmu, zeros
     uint8_t* dom_ws = nullptr;
     size_t dom_zero_bytes = 0;
-    float *P2 = nullptr, *Wtmp2 = nullptr, *cmu = nullptr, *zcoef = nullptr;
+    float *P2 = nullptr, *Wtmp2 = nullptr, *cmu = nullptr, *zcoef = nullptr, *vcross2 = nullptr;
     uint32_t* wmax2 = nullptr;
     double* vsq2 = nullptr;
     hipStream_t sA = nullptr, sB = nullptr;
@@ -130,7 +131,7 @@ struct pyrhe_engine {
     bool pending = false;         // work enqueued on the internal streams that the caller's stream has not joined yet
     void use_set(int i) {
         const WorkSet& w = sets[i];
-        ws = w.base; P = w.P; wmax = w.wmax; corr = w.corr; vsq = w.vsq; mu = w.mu; Wtmp = w.Wtmp;
+        ws = w.base; P = w.P; wmax = w.wmax; corr = w.corr; vsq = w.vsq; vcross = w.vcross; mu = w.mu; Wtmp = w.Wtmp;
         wscale = w.wscale; wfrag = w.wfrag; rows32 = w.rows32;
     }
     // profiling
@@ -245,6 +246,7 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     const size_t oCorr = carve((size_t)kMaxSeg * kSegCols * sizeof(double));
     e->zero_bytes = off;
     const size_t oVsq = carve(S * PYRHE_MAX_COLS * sizeof(double));
+    const size_t oVcr = carve(S * PYRHE_MAX_COLS * sizeof(float));
     const size_t oMu = carve(S * sizeof(float));
     const size_t oWtmp = carve(S * ncolmax * sizeof(float));
     const size_t oWscale = carve((size_t)kMaxSeg * kSegCols * sizeof(float));
@@ -255,13 +257,14 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     for (int i = 0; i < 2; ++i) {
         uint8_t* base = nullptr;
         HIPCHK_CREATE(hipMalloc(&base, e->ws_bytes));
-        HIPCHK_CREATE(hipMemset(base, 0, e->ws_bytes));
         pyrhe_engine::WorkSet& w = e->sets[i];
-        w.base = base;
+        w.base = base;                                  // owned by the engine from here on (destroy frees it if the memset fails)
+        HIPCHK_CREATE(hipMemset(base, 0, e->ws_bytes));
         w.P = (float*)(base + oP);
         w.wmax = (uint32_t*)(base + oWmax);
         w.corr = (double*)(base + oCorr);
         w.vsq = (double*)(base + oVsq);
+        w.vcross = (float*)(base + oVcr);
         w.mu = (float*)(base + oMu);
         w.Wtmp = (float*)(base + oWtmp);
         w.wscale = (float*)(base + oWscale);
@@ -314,6 +317,7 @@ extern "C" int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what) {
         case 7: return e->last_g2;
         case 8: return e->last_flow;
         case 9: return e->last_g2_merged;
+        case 10: return e->n_cross;
         default: return -1;
     }
 }
@@ -322,15 +326,18 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
                                     const float* keep, void* stream_) {
     if (!e || !R || !role_host || !keep) return fail(PYRHE_EINVAL, "NULL argument");
     if (n_cols < 1 || n_cols > PYRHE_MAX_COLS) return fail(PYRHE_EINVAL, "n_cols %d outside 1..%d", n_cols, PYRHE_MAX_COLS);
-    int ns = 0, nn = 0;
+    int ns = 0, nn = 0, nx = 0;
     for (int c = 0; c < n_cols; ++c) {
         if (role_host[c] == PYRHE_COL_SKETCH) {
-            if (nn) return fail(PYRHE_EINVAL, "sketch columns must precede norm columns (column %d)", c);
+            if (nn || nx) return fail(PYRHE_EINVAL, "sketch columns must precede norm and cross columns (column %d)", c);
             ++ns;
         } else if (role_host[c] == PYRHE_COL_NORM) {
+            if (nx) return fail(PYRHE_EINVAL, "norm columns must precede cross columns (column %d)", c);
             ++nn;
+        } else if (role_host[c] == PYRHE_COL_CROSS) {
+            ++nx;
         } else {
-            return fail(PYRHE_EINVAL, "role[%d] = %d is not SKETCH/NORM", c, role_host[c]);
+            return fail(PYRHE_EINVAL, "role[%d] = %d is not SKETCH/NORM/CROSS", c, role_host[c]);
         }
     }
     hipStream_t stream = (hipStream_t)stream_;
@@ -341,6 +348,7 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
     }
     e->n_sketch = ns;
     e->n_norm = nn;
+    e->n_cross = nx;
     e->n_user = n_cols;
     e->ntl = (n_cols + 1 + 15) / 16;
     e->nt8 = (3 * n_cols + 1 + 15) / 16;          // int8 GEMM 1: tiles of packed (digit, column) rows, see i8_slot()
@@ -422,13 +430,15 @@ static void launch_gemm2(pyrhe_engine* e, const uint8_t* packed, int n_kb, int k
 // (additive + dominance sketches, RHE_DOM).
 static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows, const int32_t* entries,
                        const int64_t* offsets_host, int nbin, const float* fill, float* out_sketch, double* out_norm,
-                       int32_t* out_colsum, int accumulate, float* out_dom, double* norm_dom, void* stream_) {
+                       int32_t* out_colsum, int accumulate, float* out_dom, double* norm_dom, double* out_cross,
+                       double* cross_dom, void* stream_) {
     if (!e || !packed || !offsets_host) return fail(PYRHE_EINVAL, "NULL argument");
     if (!e->rhs_set) return fail(PYRHE_ESTATE, "pyrhe_engine_set_rhs has not been called");
     if (nbin < 1) return fail(PYRHE_EINVAL, "nbin must be >= 1");
     if (n_rows < 0) return fail(PYRHE_EINVAL, "n_rows negative");
     if (e->n_sketch && !out_sketch) return fail(PYRHE_EINVAL, "out_sketch is NULL but there are sketch columns");
     if (e->n_norm && !out_norm) return fail(PYRHE_EINVAL, "out_norm is NULL but there are norm columns");
+    if (e->n_cross && !out_cross) return fail(PYRHE_EINVAL, "out_cross is NULL but there are cross columns (pyrhe_engine_sketch_block_cross)");
     for (int b = 0; b < nbin; ++b) {
         if (offsets_host[b + 1] < offsets_host[b]) return fail(PYRHE_EINVAL, "offsets not monotone at bin %d", b);
         if (offsets_host[b + 1] - offsets_host[b] > e->max_entries)
@@ -440,8 +450,9 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     if (n_rows >= (1ll << 31) || e->pitch >= (1 << 24) || (wide_rows && !e->opt_list_span))
         return fail(PYRHE_EINVAL, "block of %lld rows x %lld bytes exceeds the 32-bit row offsets of one call; split it",
                     (long long)n_rows, (long long)e->pitch);
-    const bool dom = out_dom != nullptr || norm_dom != nullptr;
-    if (dom && ((e->n_sketch && !out_dom) || (e->n_norm && !norm_dom))) return fail(PYRHE_EINVAL, "dominance outputs incomplete");
+    const bool dom = out_dom != nullptr || norm_dom != nullptr || cross_dom != nullptr;
+    if (dom && ((e->n_sketch && !out_dom) || (e->n_norm && !norm_dom) || (e->n_cross && !cross_dom))) return fail(PYRHE_EINVAL, "dominance outputs incomplete");
+    const int64_t cr_stride = (int64_t)e->n_cross * e->n_cross;
     hipStream_t caller = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(e->device));
     // Serial mode (default): everything goes to the caller's stream, no events.  Pipelined mode: private streams A
@@ -489,6 +500,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         const size_t oW2 = carve(S * nc * sizeof(float));
         const size_t oCm = carve(S * sizeof(float));
         const size_t oZc = carve(S * sizeof(float));
+        const size_t oVc2 = carve(S * PYRHE_MAX_COLS * sizeof(float));
         HIPCHK(hipMalloc(&e->dom_ws, off));
         HIPCHK(hipMemset(e->dom_ws, 0, off));
         e->P2 = (float*)(e->dom_ws + oP2);
@@ -497,6 +509,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         e->Wtmp2 = (float*)(e->dom_ws + oW2);
         e->cmu = (float*)(e->dom_ws + oCm);
         e->zcoef = (float*)(e->dom_ws + oZc);
+        e->vcross2 = (float*)(e->dom_ws + oVc2);
     }
 
     // zero P for the n entries of this launch (not the whole sub_snps-sized buffer: 25 MB per call at 65536 entries) and the
@@ -678,7 +691,12 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             const int want = (g2p_merge && g2p_ok && gv == 0) ? std::max(1, (int)((int64_t)tab.nseg * g2p_gx / e->opt_g2_merge)) : 1;   // segments per group
             for (int g = 0; g < tab.nseg;) {
                 int kbs = tab.kb0[g + 1] - tab.kb0[g], n = 1;
-                while (g + n < tab.nseg && n < want && g2p_lds(kbs + tab.kb0[g + n + 1] - tab.kb0[g + n], n + 1, lds_ng) <= 65536) {
+                // A merged group is addressed relative to the lowest row of ALL its lists (32-bit offsets inside): in a call
+                // beyond the 32-bit row span only lists the caller vouched for TOGETHER may share one -- the opt_list_span
+                // consecutive lists from a multiple of it (the bins of one jackknife block), never the last bins of one block
+                // with the first of the next.
+                while (g + n < tab.nseg && n < want && (!wide_rows || tab.bin[g + n] / e->opt_list_span == tab.bin[g] / e->opt_list_span) &&
+                       g2p_lds(kbs + tab.kb0[g + n + 1] - tab.kb0[g + n], n + 1, lds_ng) <= 65536) {
                     kbs += tab.kb0[g + n + 1] - tab.kb0[g + n];
                     ++n;
                 }
@@ -764,6 +782,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             if (offsets_host[b + 1] == offsets_host[b] && !accumulate) {
                 if (out_sketch) HIPCHK(hipMemsetAsync(out_sketch + b * sk_stride, 0, sk_stride * sizeof(float), sB2));
                 if (out_norm && e->n_norm) HIPCHK(hipMemsetAsync(out_norm + (int64_t)b * e->n_norm, 0, e->n_norm * sizeof(double), stream));
+                if (e->n_cross) HIPCHK(hipMemsetAsync(out_cross + b * cr_stride, 0, cr_stride * sizeof(double), stream));
             }
         const int64_t total = offsets_host[nbin];
         const int64_t seg_cap = std::min<int64_t>(e->sub_snps, kG2pSegCap);   // GEMM 2 keeps a segment's row list in LDS
@@ -802,7 +821,9 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 ProfScope ps(e, stream, 1);
                 mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
                                                                  (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->vsq,
-                                                                 out_colsum ? out_colsum + chunk0 : nullptr, tab);
+                                                                 out_colsum ? out_colsum + chunk0 : nullptr, e->n_cross, e->vcross, tab);
+                if (e->n_cross)
+                    cross_reduce_kernel<<<tab.nseg * (e->n_cross * (e->n_cross + 1) / 2), 256, 0, stream>>>(e->vcross, e->n_cross, out_cross, tab);
             }
             if (e->n_sketch) {
                 const int rc = run_gemm2(0, e->Wtmp, e->mu, e->wmax, n, kb, out_sketch, false, set, rows, e->n_norm ? e->vsq : nullptr,
@@ -825,12 +846,16 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         double* normb = out_norm ? out_norm + (int64_t)b * e->n_norm : nullptr;
         float* outd = out_dom ? out_dom + b * sk_stride : nullptr;
         double* normd = norm_dom ? norm_dom + (int64_t)b * e->n_norm : nullptr;
+        double* crossb = out_cross ? out_cross + b * cr_stride : nullptr;
+        double* crossd = cross_dom ? cross_dom + b * cr_stride : nullptr;
         if (n_b == 0) {
             if (!accumulate) {
                 if (outb) HIPCHK(hipMemsetAsync(outb, 0, sk_stride * sizeof(float), sB2));
                 if (normb && e->n_norm) HIPCHK(hipMemsetAsync(normb, 0, e->n_norm * sizeof(double), stream));
                 if (outd) HIPCHK(hipMemsetAsync(outd, 0, sk_stride * sizeof(float), sB2));
                 if (normd && e->n_norm) HIPCHK(hipMemsetAsync(normd, 0, e->n_norm * sizeof(double), stream));
+                if (crossb && e->n_cross) HIPCHK(hipMemsetAsync(crossb, 0, cr_stride * sizeof(double), stream));
+                if (crossd && e->n_cross) HIPCHK(hipMemsetAsync(crossd, 0, cr_stride * sizeof(double), stream));
             }
             continue;
         }
@@ -864,8 +889,9 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 ProfScope ps(e, stream, 1);
                 mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
                                                                  (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->vsq,
-                                                                 out_colsum ? out_colsum + offsets_host[b] + s0 : nullptr, tab);
+                                                                 out_colsum ? out_colsum + offsets_host[b] + s0 : nullptr, e->n_cross, e->vcross, tab);
                 if (e->n_norm && !e->n_sketch) norm_reduce_kernel<<<e->n_norm, 256, 0, stream>>>(e->vsq, e->n_norm, normb, tab);
+                if (e->n_cross) cross_reduce_kernel<<<e->n_cross * (e->n_cross + 1) / 2, 256, 0, stream>>>(e->vcross, e->n_cross, crossb, tab);
             }
             if (!e->n_sketch && piped) {
                 HIPCHK(hipEventRecord(e->evA[set], e->sA));
@@ -888,8 +914,9 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                     ProfScope ps(e, stream, 1);
                     mid_dom1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->P2, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale,
                                                                          e->csum, (float)e->n_keep, e->cmu, e->Wtmp, e->Wtmp2, e->wmax, e->wmax2,
-                                                                         e->vsq2);
+                                                                         e->vsq2, e->n_cross, e->vcross2);
                     if (e->n_norm && !e->n_sketch) norm_reduce_kernel<<<e->n_norm, 256, 0, stream>>>(e->vsq2, e->n_norm, normd, tab);
+                    if (e->n_cross) cross_reduce_kernel<<<e->n_cross * (e->n_cross + 1) / 2, 256, 0, stream>>>(e->vcross2, e->n_cross, crossd, tab);
                 }
                 if (e->n_sketch) {
                     int rc = run_gemm2(0, e->Wtmp, e->cmu, e->wmax, n, n_kb, outd, acc_now, set, rows, e->n_norm ? e->vsq2 : nullptr,
@@ -924,7 +951,7 @@ extern "C" int pyrhe_engine_sketch_block(pyrhe_engine_t* e, const uint8_t* packe
                                          const float* fill, float* out_sketch, double* out_norm,
                                          int32_t* out_colsum, int accumulate, void* stream_) {
     return sketch_impl(e, packed, n_rows, entries, offsets_host, nbin, fill, out_sketch, out_norm, out_colsum, accumulate,
-                       nullptr, nullptr, stream_);
+                       nullptr, nullptr, nullptr, nullptr, stream_);
 }
 
 extern "C" int pyrhe_engine_sketch_block_dom(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
@@ -934,7 +961,18 @@ extern "C" int pyrhe_engine_sketch_block_dom(pyrhe_engine_t* e, const uint8_t* p
                                              void* stream_) {
     if (!out_sketch_dom && !out_norm_dom) return fail(PYRHE_EINVAL, "dominance outputs are NULL");
     return sketch_impl(e, packed, n_rows, entries, offsets_host, nbin, fill, out_sketch, out_norm, nullptr, accumulate,
-                       out_sketch_dom, out_norm_dom, stream_);
+                       out_sketch_dom, out_norm_dom, nullptr, nullptr, stream_);
+}
+
+extern "C" int pyrhe_engine_sketch_block_cross(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
+                                               const int32_t* entries, const int64_t* offsets_host, int nbin,
+                                               const float* fill, float* out_sketch, double* out_norm, double* out_cross,
+                                               float* out_sketch_dom, double* out_norm_dom, double* out_cross_dom,
+                                               int accumulate, void* stream_) {
+    if (e && !e->n_cross) return fail(PYRHE_ESTATE, "no PYRHE_COL_CROSS columns installed (pyrhe_engine_set_rhs)");
+    if (!out_cross) return fail(PYRHE_EINVAL, "out_cross is NULL");
+    return sketch_impl(e, packed, n_rows, entries, offsets_host, nbin, fill, out_sketch, out_norm, nullptr, accumulate,
+                       out_sketch_dom, out_norm_dom, out_cross, out_cross_dom, stream_);
 }
 
 extern "C" int pyrhe_engine_set_async(pyrhe_engine_t* e, int enable) {
@@ -963,7 +1001,9 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
             e->opt_g1_wide = (int)value; break;
         case PYRHE_OPT_G1_ZERO_ROWS: e->opt_g1_zero_rows = value != 0; break;
         case PYRHE_OPT_G1_FILL: e->opt_g1_fill = value != 0; break;
-        case PYRHE_OPT_LIST_SPAN: e->opt_list_span = value != 0; break;
+        case PYRHE_OPT_LIST_SPAN:
+            if (value < 0 || value > (1 << 20)) return fail(PYRHE_EINVAL, "LIST_SPAN %lld outside 0..2^20", (long long)value);
+            e->opt_list_span = (int)value; break;
         case PYRHE_OPT_G2_MERGE:
             if (value < 0 || value > (1 << 20)) return fail(PYRHE_EINVAL, "G2_MERGE %lld outside 0..2^20", (long long)value);
             e->opt_g2_merge = (int)value; break;

@@ -22,6 +22,7 @@ PREC_I8X3 = 3
 PRECISIONS = {"f16": PREC_F16, "f16x2": PREC_F16X2, "f16e": PREC_F16_EXACT, "i8x3": PREC_I8X3, "i8f16": 4}
 COL_SKETCH = 1
 COL_NORM = 2
+COL_CROSS = 3
 ROW_ALIGN = 256           # pitch granularity (bytes)
 
 _lib = None
@@ -36,6 +37,7 @@ SYMBOLS = {
     "pyrhe_engine_set_rhs": (_i32, [_vp, _vp, C.POINTER(C.c_int32), _i32, _vp, _vp]),
     "pyrhe_engine_sketch_block": (_i32, [_vp, _vp, _i64, _vp, C.POINTER(_i64), _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "pyrhe_engine_sketch_block_dom": (_i32, [_vp, _vp, _i64, _vp, C.POINTER(_i64), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "pyrhe_engine_sketch_block_cross": (_i32, [_vp, _vp, _i64, _vp, C.POINTER(_i64), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "pyrhe_engine_block_stats": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "pyrhe_engine_set_async": (_i32, [_vp, _i32]),
     "pyrhe_engine_join": (_i32, [_vp, _vp]),
@@ -246,6 +248,7 @@ class SketchEngine:
         self.n_sketch = 0
         self.options = {}             # knobs set through set_option (the library's defaults otherwise)
         self.n_norm = 0
+        self.n_cross = 0
         self._keep = None
         self._rhs = None
 
@@ -271,26 +274,31 @@ class SketchEngine:
             keep[torch.as_tensor(list(missing_indv), device=self.device, dtype=torch.long)] = 0.0
         return keep
 
-    def set_rhs(self, sketch_cols: Optional[torch.Tensor], norm_cols: Optional[torch.Tensor], keep: torch.Tensor):
-        """sketch_cols ``[n_sketch, n_pad]`` / norm_cols ``[n_norm, n_pad]`` float32 on the device, zero at
-        dropped and padding samples."""
-        parts = [t for t in (sketch_cols, norm_cols) if t is not None and t.shape[0] > 0]
+    def set_rhs(self, sketch_cols: Optional[torch.Tensor], norm_cols: Optional[torch.Tensor], keep: torch.Tensor,
+                cross_cols: Optional[torch.Tensor] = None):
+        """sketch_cols ``[n_sketch, n_pad]`` / norm_cols ``[n_norm, n_pad]`` / cross_cols ``[n_cross, n_pad]`` float32 on the
+        device, zero at dropped and padding samples."""
+        parts = [t for t in (sketch_cols, norm_cols, cross_cols) if t is not None and t.shape[0] > 0]
         R = torch.cat(parts, dim=0).to(torch.float32).contiguous()
         assert R.shape[1] == self.n_pad and R.device == self.device
         ns = 0 if sketch_cols is None else sketch_cols.shape[0]
         nn = 0 if norm_cols is None else norm_cols.shape[0]
-        roles = (C.c_int32 * (ns + nn))(*([COL_SKETCH] * ns + [COL_NORM] * nn))
+        nx = 0 if cross_cols is None else cross_cols.shape[0]
+        roles = (C.c_int32 * (ns + nn + nx))(*([COL_SKETCH] * ns + [COL_NORM] * nn + [COL_CROSS] * nx))
         keep = keep.to(torch.float32).contiguous()
         with torch.cuda.device(self.device):
-            _check(self.lib.pyrhe_engine_set_rhs(self._h, _ptr(R), roles, ns + nn, _ptr(keep), _stream_ptr(self.device)),
+            _check(self.lib.pyrhe_engine_set_rhs(self._h, _ptr(R), roles, ns + nn + nx, _ptr(keep), _stream_ptr(self.device)),
                    "pyrhe_engine_set_rhs")
-        self.n_sketch, self.n_norm = ns, nn
+        self.n_sketch, self.n_norm, self.n_cross = ns, nn, nx
         self._rhs, self._keep = R, keep      # keep alive until the async prep has run
 
     def sketch_block(self, packed: torch.Tensor, entries: torch.Tensor, offsets: Sequence[int], *,
                      fill: Optional[torch.Tensor] = None, out_sketch: Optional[torch.Tensor] = None,
-                     out_norm: Optional[torch.Tensor] = None, accumulate: bool = False, want_colsum: bool = False):
-        """Enqueue the sketch of one block; returns ``(out_sketch [nbin, n_sketch, n_pad], out_norm [nbin, n_norm], colsum|None)``."""
+                     out_norm: Optional[torch.Tensor] = None, accumulate: bool = False, want_colsum: bool = False,
+                     out_cross: Optional[torch.Tensor] = None):
+        """Enqueue the sketch of one block; returns ``(out_sketch [nbin, n_sketch, n_pad], out_norm [nbin, n_norm], colsum|None)``.
+        With cross columns installed ``out_cross [nbin, n_cross, n_cross]`` float64 receives their Gram matrices
+        (``pyrhe_engine_sketch_block_cross``)."""
         nbin = len(offsets) - 1
         assert packed.dtype == torch.uint8 and packed.is_contiguous() and packed.shape[1] == self.pitch
         assert entries.dtype == torch.int32 and entries.is_contiguous()
@@ -302,6 +310,15 @@ class SketchEngine:
             assert not accumulate
         colsum = torch.empty(int(offsets[-1]), dtype=torch.int32, device=self.device) if want_colsum else None
         offs = (C.c_int64 * (nbin + 1))(*[int(o) for o in offsets])
+        if self.n_cross:
+            assert not want_colsum and out_cross is not None and out_cross.dtype == torch.float64 and out_cross.is_contiguous()
+            assert out_cross.numel() == nbin * self.n_cross * self.n_cross
+            with torch.cuda.device(self.device):
+                _check(self.lib.pyrhe_engine_sketch_block_cross(self._h, _ptr(packed), packed.shape[0], _ptr(entries), offs, nbin,
+                                                                _ptr(fill), _ptr(out_sketch), _ptr(out_norm), _ptr(out_cross),
+                                                                None, None, None, 1 if accumulate else 0,
+                                                                _stream_ptr(self.device)), "pyrhe_engine_sketch_block_cross")
+            return out_sketch, out_norm, None
         with torch.cuda.device(self.device):
             _check(self.lib.pyrhe_engine_sketch_block(self._h, _ptr(packed), packed.shape[0], _ptr(entries), offs, nbin,
                                                       _ptr(fill), _ptr(out_sketch), _ptr(out_norm), _ptr(colsum),
@@ -311,8 +328,9 @@ class SketchEngine:
 
     def sketch_block_dom(self, packed: torch.Tensor, entries: torch.Tensor, offsets: Sequence[int], *,
                          fill: Optional[torch.Tensor] = None, out_sketch=None, out_norm=None, out_sketch_dom=None,
-                         out_norm_dom=None, accumulate: bool = False):
-        """Additive + dominance (RHE_DOM) sketches of one block; returns the four output tensors."""
+                         out_norm_dom=None, accumulate: bool = False, out_cross=None, out_cross_dom=None):
+        """Additive + dominance (RHE_DOM) sketches of one block; returns the four output tensors (with cross columns
+        installed their Gram matrices under both encodings go to ``out_cross`` / ``out_cross_dom``)."""
         nbin = len(offsets) - 1
         assert packed.dtype == torch.uint8 and packed.is_contiguous() and packed.shape[1] == self.pitch
 
@@ -326,6 +344,15 @@ class SketchEngine:
         out_norm = _mk(out_norm, (nbin, max(self.n_norm, 1)), torch.float64)
         out_norm_dom = _mk(out_norm_dom, (nbin, max(self.n_norm, 1)), torch.float64)
         offs = (C.c_int64 * (nbin + 1))(*[int(o) for o in offsets])
+        if self.n_cross:
+            assert out_cross is not None and out_cross_dom is not None
+            with torch.cuda.device(self.device):
+                _check(self.lib.pyrhe_engine_sketch_block_cross(self._h, _ptr(packed), packed.shape[0], _ptr(entries), offs, nbin,
+                                                                _ptr(fill), _ptr(out_sketch), _ptr(out_norm), _ptr(out_cross),
+                                                                _ptr(out_sketch_dom), _ptr(out_norm_dom), _ptr(out_cross_dom),
+                                                                1 if accumulate else 0, _stream_ptr(self.device)),
+                       "pyrhe_engine_sketch_block_cross")
+            return out_sketch, out_norm, out_sketch_dom, out_norm_dom
         with torch.cuda.device(self.device):
             _check(self.lib.pyrhe_engine_sketch_block_dom(self._h, _ptr(packed), packed.shape[0], _ptr(entries), offs, nbin,
                                                           _ptr(fill), _ptr(out_sketch), _ptr(out_norm), _ptr(out_sketch_dom),

@@ -39,8 +39,9 @@ class Base:
                  multiprocessing: bool = True, seed: Optional[int] = None, get_trace: bool = False,
                  trace_dir: Optional[str] = None, samp_prev: Optional[float] = None, pop_prev: Optional[float] = None,
                  log: Optional[Logger] = None, precision: str = "i8x3", compat: str = "reference",
-                 recompute_pass2: bool = False, sub_snps: int = 0):
+                 recompute_pass2: bool = False, sub_snps: int = 0, materialize_xxuz: bool = False):
         self.model = model
+        self.materialize_xxuz = bool(materialize_xxuz)
         self.num_jack = self.num_blocks = int(num_jack)
         self.num_random_vec = int(num_random_vec)
         self.geno_impute_methods = geno_impute_method
@@ -64,10 +65,13 @@ class Base:
         # SAME probe vectors, generated annotation and imputation stream: an unset seed is chosen on rank 0 and broadcast.
         self.seed = int(time.process_time()) if seed is None else int(seed)
         if self.world > 1:
+            given = [None] * self.world              # every rank sees every rank's seed, so that ALL of them raise on a mismatch
+            dist.all_gather_object(given, None if seed is None else int(seed))      # (one raising alone leaves the others in a collective)
             box = [self.seed]
             dist.broadcast_object_list(box, src=0)
-            if seed is not None and int(box[0]) != self.seed:
-                raise ValueError(f"rank {self.rank} was given seed {self.seed}, rank 0 seed {box[0]}: all ranks need the same seed")
+            bad = [(r, s_) for r, s_ in enumerate(given) if s_ is not None and s_ != int(box[0])]
+            if bad:
+                raise ValueError(f"ranks were given different seeds (rank 0 uses {box[0]}; differing: {bad}): all ranks need the same seed")
             self.seed = int(box[0])
         rs = np.random.RandomState(self.seed)
 
@@ -161,7 +165,8 @@ class Base:
                             missing_indv=self.missing_indv, Z=self.all_zb, cov=self.cov_matrix, env=self.env,
                             genie_model=self.genie_model, impute=self.geno_impute_methods, seed=self.seed,
                             streaming=self.streaming, compat=self.compat, recompute_pass2=self.recompute_pass2,
-                            rng_prefix_draws=self._rng_prefix, rng_prefix_high=self._rng_high)
+                            rng_prefix_draws=self._rng_prefix, rng_prefix_high=self._rng_high,
+                            materialize_xxuz=self.materialize_xxuz)
 
     def pre_compute(self):
         t0 = time.time()
@@ -314,7 +319,8 @@ class RHE_DOM(Base):
         return SketchRunner(self._engines, self.geno_dev, self.plan, self.local_blocks, n_orig=self.num_indv_original,
                             missing_indv=self.missing_indv, Z=self.all_zb, cov=self.cov_matrix, impute=self.geno_impute_methods,
                             seed=self.seed, streaming=self.streaming, compat=self.compat, recompute_pass2=self.recompute_pass2,
-                            rng_prefix_draws=self._rng_prefix, rng_prefix_high=self._rng_high, dom=True)
+                            rng_prefix_draws=self._rng_prefix, rng_prefix_high=self._rng_high,
+                            materialize_xxuz=self.materialize_xxuz, dom=True)
 
     def run(self, method):
         log = self.log._log
@@ -390,7 +396,8 @@ class GENIE(Base):
                             missing_indv=self.missing_indv, Z=self.all_zb, cov=self.cov_matrix, env=self.env,
                             genie_model=self.genie_model, impute=self.geno_impute_methods, seed=self.seed,
                             streaming=self.streaming, compat=self.compat, recompute_pass2=self.recompute_pass2,
-                            rng_prefix_draws=self._rng_prefix, rng_prefix_high=self._rng_high)
+                            rng_prefix_draws=self._rng_prefix, rng_prefix_high=self._rng_high,
+                            materialize_xxuz=self.materialize_xxuz)
 
     def estimate(self, method: str = "lstsq"):
         """Variance components and their trace-adjusted copies sigma_i * T[i, ne] (genie.py:97-144)."""

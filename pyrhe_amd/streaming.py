@@ -113,11 +113,28 @@ def engine_capacity(plan: "BlockPlan") -> int:
     return max(int(plan.max_block), int(os.environ.get("PYRHE_CAPACITY", "131072")))
 
 
-def plan_passes(k: int, n_groups: int, n_norm: int):
+def plan_passes(k: int, n_groups: int, n_norm: int, cross=()):
     """Distribute ``n_groups`` groups of ``k`` sketch columns (Z, UZ, e.Z, e.UZ) and ``n_norm`` norm columns (all in
     pass 0) over engine passes of at most 30 right-hand columns.  A group stays whole when it fits into the current
     pass or into a fresh one; only groups wider than a pass (num_random_vec > 30 - n_norm) are split.
-    Returns, per pass, a list of chunks ``(group index, first column s0, number of columns)``."""
+    Returns, per pass, a list of chunks ``(group index, first column s0, number of columns)``.
+    ``cross``: sizes of cross-column groups (the covariates W, e.W: each stays whole, its Gram matrix needs all pairs in one
+    pass); then the result is ``(passes, cross_at)`` with ``cross_at[i] = (pass, first cross column of that pass)`` -- the
+    first pass with room, or a pass of its own (one GEMM 1 over the genotypes, no GEMM 2)."""
+    if cross:
+        passes = plan_passes(k, n_groups, n_norm)
+        free = [MAX_ENGINE_COLS - sum(nc for _, _, nc in ch) - (n_norm if pi == 0 else 0) for pi, ch in enumerate(passes)]
+        used, cross_at = [0] * len(passes), []
+        for c in cross:
+            if c > MAX_ENGINE_COLS:
+                raise ValueError(f"a cross group of {c} columns does not fit one engine pass")
+            pi = next((i for i, f in enumerate(free) if f >= c), None)
+            if pi is None:
+                passes.append([]); free.append(MAX_ENGINE_COLS); used.append(0)
+                pi = len(passes) - 1
+            cross_at.append((pi, used[pi]))
+            used[pi] += c; free[pi] -= c
+        return passes, cross_at
     passes, free = [[]], [MAX_ENGINE_COLS - n_norm]
     for g in range(n_groups):
         if k <= free[-1]:
@@ -136,7 +153,20 @@ def plan_passes(k: int, n_groups: int, n_norm: int):
 
 
 def n_engines_needed(k: int, use_cov: bool, has_gxe: bool) -> int:
+    """Engines (= passes over the genotypes) with the U Z sketch columns materialised; the covariates-as-cross-columns
+    form is only chosen when it needs no more (SketchRunner.cross)."""
     return len(plan_passes(k, (2 if use_cov else 1) * (2 if has_gxe else 1), 2 if has_gxe else 1))
+
+
+def cross_columns_pay(k: int, c: int, has_gxe: bool) -> bool:
+    """Whether the covariates go in as CROSS columns (c more columns in GEMM 1, their c x c Gram per (block, bin) out)
+    instead of the k sketch columns U Z (k more columns in both contractions, [k, N] rows per (block, bin) out): when that
+    takes no more passes over the genotypes than the materialised form."""
+    if c < 1 or c > MAX_ENGINE_COLS:
+        return False
+    g = 2 if has_gxe else 1
+    passes, _ = plan_passes(k, g, g, cross=[c] * g)
+    return len(passes) <= n_engines_needed(k, True, has_gxe)
 
 
 class SketchRunner:
@@ -157,7 +187,7 @@ class SketchRunner:
                  env: Optional[np.ndarray] = None, genie_model: Optional[str] = None,
                  impute: str = "binary", seed: int = 0, streaming: bool = True, compat: str = "reference",
                  recompute_pass2: bool = False, rng_prefix_draws: int = 0, group=None, dom: bool = False,
-                 solo: bool = False, rng_prefix_high: int = 2):
+                 solo: bool = False, rng_prefix_high: int = 2, materialize_xxuz: bool = False):
         self.engs = list(engines) if isinstance(engines, (list, tuple)) else [engines]
         self.eng = self.engs[0]
         self.geno = geno
@@ -216,6 +246,15 @@ class SketchRunner:
             self.UZ64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.UZ.T)))  # [k, n_pad]
             self.WT64 = self.W64.T.contiguous()                                              # [c, n_pad]
             self.WT32 = self.WT64.to(torch.float32)
+        # Covariates: XXUz = X X^T (U Z) enters the normal equations only through sum(XXUz * UXXz) (base.py:589-591) and
+        # UXXz lies in span(W), so only W^T XXUz = (W^T X X^T W)(Q W^T Z) is needed: the c covariate columns go through the
+        # first contraction as CROSS columns and the engine returns S = W^T X X^T W per (block, bin) -- no U Z sketch
+        # columns, half the second contraction, half the stored rows.  ``materialize_xxuz``: the k U Z sketch columns
+        # instead (the reference's own arrays; block-wise XXUz tests, or more covariates than a pass has room for).
+        self.cross = (self.cov is not None and not materialize_xxuz and
+                      cross_columns_pay(self.k, self.cov.shape[1], self.n_gxe > 0))
+        if self.cross:
+            self.G64 = torch.from_numpy(self.Q @ (self.cov.T @ self.Z)).to(self.device)      # [c, k]: U Z = W G
         self.Z64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.Z.T)))        # [k, n_pad] f64
         if self.env is not None:
             self.env_pad = self._pad_cols(torch.from_numpy(self.env[None, :]))[0]            # [n_pad] f64
@@ -257,23 +296,33 @@ class SketchRunner:
             raise ValueError(f"{nt} phenotypes do not fit the spare right-hand columns of one pass ({self.max_traits()})")
         ypad = self._pad_cols(torch.from_numpy(np.ascontiguousarray(y64.T)))     # [n_traits, n_pad]
         names, groups, norms = ["Z"], [self.Z64], [ypad]
-        if use_cov:
+        cnames, cgroups = [], []                 # cross columns: the covariates W (and e.W for the G x E estimates)
+        if use_cov and self.cross:
+            cnames.append("W"); cgroups.append(self.WT64)
+        elif use_cov:
             names.append("UZ"); groups.append(self.UZ64)
         if self.n_gxe:
             e = self.env_pad
             names.append("eZ"); groups.append(self.Z64 * e)
-            if use_cov:
+            if use_cov and self.cross:           # X_e X_e^T (U Z) = e.(X X^T (e.W)) G: W^T of it is the Gram of the columns e.W
+                cnames.append("eW"); cgroups.append(self.WT64 * e)
+            elif use_cov:
                 names.append("eUZ"); groups.append(self.UZ64 * e)
             norms.append(ypad * e)
         k = self.k
-        passes = plan_passes(k, len(groups), sum(n.shape[0] for n in norms))
+        n_norm_all = sum(n.shape[0] for n in norms)
+        if cgroups:
+            passes, cross_at = plan_passes(k, len(groups), n_norm_all, cross=[g.shape[0] for g in cgroups])
+        else:
+            passes, cross_at = plan_passes(k, len(groups), n_norm_all), []
         if len(passes) > len(self.engs):
             raise RuntimeError(f"{len(groups)} groups of {k} right-hand columns need {len(passes)} engines, "
                                f"{len(self.engs)} given")
         # where each logical group lives: a list of chunks (pass, first engine column, first group column s0, count);
         # norm columns: (pass, column).  `breaks`: the common refinement of all chunk boundaries (pass 2 walks it).
         self.loc = {n: [] for n in names}
-        self.pass_shapes = []
+        self.cross_loc = {n: (cp, c0, cgroups[i].shape[0]) for i, (n, (cp, c0)) in enumerate(zip(cnames, cross_at))}
+        self.pass_shapes, self.pass_cross = [], []
         breaks = {0, k}
         for pi, chunks in enumerate(passes):
             col, parts = 0, []
@@ -284,8 +333,13 @@ class SketchRunner:
                 col += nc
             sk = torch.cat(parts, dim=0).to(torch.float32) if parts else None
             nm = torch.cat(norms, dim=0).to(torch.float32) if pi == 0 else None
-            self.engs[pi].set_rhs(sk, nm, self.keep)
-            self.pass_shapes.append((col, sum(n.shape[0] for n in norms) if pi == 0 else 0))
+            cr = [cgroups[i] for i, (cp, _) in enumerate(cross_at) if cp == pi]
+            if cr:
+                self.engs[pi].set_rhs(sk, nm, self.keep, cross_cols=torch.cat(cr, dim=0).to(torch.float32))
+            else:
+                self.engs[pi].set_rhs(sk, nm, self.keep)
+            self.pass_shapes.append((col, n_norm_all if pi == 0 else 0))
+            self.pass_cross.append(sum(g.shape[0] for g in cr))
         self.loc["y"] = (0, 0)                 # norm columns of pass 0: y of every phenotype, then e.y of every phenotype
         if self.n_gxe:
             self.loc["ey"] = (0, nt)
@@ -393,8 +447,11 @@ class SketchRunner:
                 from .engine import OPTIONS
                 ok = "list_span" in OPTIONS
             if ok:
+                # the engine may let lists share a GEMM 2 workgroup (addressed from their common lowest row) only inside one
+                # window of n_bin consecutive lists = the bins of ONE block: every block fits the 32-bit span (_pieces
+                # otherwise), two neighbouring blocks need not (N = 500k: blocks of more than 17 154 SNPs)
                 for e_ in self.engs[:self.n_pass]:
-                    e_.set_option("list_span", 1)
+                    e_.set_option("list_span", self.plan.n_bin)
             self._span_ok = bool(ok)
         return self._span_ok
 
@@ -431,13 +488,17 @@ class SketchRunner:
             self._entries_cache[key] = out
         return self._entries_cache[key]
 
-    def _sketch_call(self, p: int, rows, ent, offs, fill, osk, onm, oskd=None, onmd=None, accumulate=False):
-        """One engine call of pass ``p`` (additive, or additive + dominance for RHE_DOM) into the given outputs."""
+    def _sketch_call(self, p: int, rows, ent, offs, fill, osk, onm, oskd=None, onmd=None, accumulate=False, ocr=None, ocrd=None):
+        """One engine call of pass ``p`` (additive, or additive + dominance for RHE_DOM) into the given outputs (``ocr`` /
+        ``ocrd``: the Gram matrices of the pass's cross columns, when it has any)."""
+        kw = {} if ocr is None else {"out_cross": ocr}
         if self.dom:
+            if ocrd is not None:
+                kw["out_cross_dom"] = ocrd
             self.engs[p].sketch_block_dom(rows, ent, offs, fill=fill, out_sketch=osk, out_norm=onm, out_sketch_dom=oskd,
-                                          out_norm_dom=onmd, accumulate=accumulate)
+                                          out_norm_dom=onmd, accumulate=accumulate, **kw)
         else:
-            self.engs[p].sketch_block(rows, ent, offs, fill=fill, out_sketch=osk, out_norm=onm, accumulate=accumulate)
+            self.engs[p].sketch_block(rows, ent, offs, fill=fill, out_sketch=osk, out_norm=onm, accumulate=accumulate, **kw)
 
     def _batch_entries(self, js):
         """Entry lists of the blocks ``js`` (consecutive) as ONE call: row indices relative to the first row of the batch,
@@ -507,20 +568,26 @@ class SketchRunner:
                         fills.append(fill)
                 pieces = self._pieces(js[0]) if len(js) == 1 else None
                 for p in range(self.n_pass):
+                    has_cr = self.pass_cross[p] > 0
+                    ocr = self.blocks_cr[p][jl] if has_cr else None
+                    ocrd = self.blocks_crd[p][jl] if (has_cr and self.dom) else None
                     if pieces is not None:          # a block beyond the 32-bit row offsets of one call: row sub-ranges
                         for i_, (a, b, ent_p, offs_p) in enumerate(pieces):
                             self._sketch_call(p, rows[a:b], ent_p, offs_p, None if fill is None else fill[a:b].contiguous(),
                                               out_sk[p][jl], out_norm[p][jl], self.blocks_skd[p][jl] if self.dom else None,
-                                              self.blocks_nmd[p][jl] if self.dom else None, accumulate=i_ > 0)
+                                              self.blocks_nmd[p][jl] if self.dom else None, accumulate=i_ > 0, ocr=ocr, ocrd=ocrd)
                     elif self.dom:
                         self._sketch_call(p, rows, ent, offs, fill, out_sk[p][jl], out_norm[p][jl], self.blocks_skd[p][jl],
-                                          self.blocks_nmd[p][jl])
+                                          self.blocks_nmd[p][jl], ocr=ocr, ocrd=ocrd)
                     else:
                         n = len(js)
                         osk = out_sk[p][jl:jl + n]
                         onm = out_norm[p][jl:jl + n]
+                        if has_cr:
+                            ocr = self.blocks_cr[p][jl:jl + n]
+                            ocr = ocr.reshape(n * nb, *ocr.shape[2:])
                         self._sketch_call(p, rows, ent, offs, fill, osk.reshape(n * nb, *osk.shape[2:]),
-                                          onm.reshape(n * nb, onm.shape[2]))
+                                          onm.reshape(n * nb, onm.shape[2]), ocr=ocr)
                 if one_slot:
                     after_block(jl0, js[0])
         finally:
@@ -532,7 +599,10 @@ class SketchRunner:
         """``W (Q (W^T v))`` for rows of v ``[..., n_pad]``; float32 like _compute_UXXz (base.py:407-408) or float64
         like setup_lhs_rhs_jackknife (base.py:584-586).  Result float64."""
         proj = getattr(self.eng, "apply_projector", None)
-        if f32 and proj is not None:          # the HIP kernels (pyrhe_engine_apply_projector); stand-in engines of the CPU tests lack them
+        n_rows = v.numel() // max(v.shape[-1], 1)
+        # the HIP kernels (pyrhe_engine_apply_projector: <= 64 covariates, < 65 536 rows per call; wider covariate sets take the
+        # torch float32 chain below); stand-in engines of the CPU tests lack them
+        if f32 and proj is not None and self.WT32.shape[0] <= 64 and n_rows <= 65535:
             return proj(v.to(torch.float64).contiguous(), self.WT32, self.Q32)
         W, Q = (self.W32, self.Q32) if f32 else (self.W64, self.Q64)
         x = v.to(W.dtype)
@@ -545,8 +615,13 @@ class SketchRunner:
         """Phenotypes one pass can take: the sketches X X^T Z do not depend on the phenotype, a phenotype only adds a norm
         column (two with G x E), so the spare right-hand columns of the first engine pass carry further phenotypes for free
         (k = 10: 20 without covariates, 10 with; the reference re-runs everything per phenotype)."""
-        n_groups = (2 if self.cov is not None else 1) * (2 if self.n_gxe else 1)
         per = 2 if self.n_gxe else 1
+        if self.cov is not None and self.cross:      # the cross columns that share pass 0 with one phenotype stay there
+            c = self.cov.shape[1]
+            passes, cross_at = plan_passes(self.k, per, per, cross=[c] * per)
+            used = sum(nc for _, _, nc in passes[0]) + sum(c for cp, _ in cross_at if cp == 0)
+            return max(1, (MAX_ENGINE_COLS - used) // per)
+        n_groups = (2 if self.cov is not None else 1) * (2 if self.n_gxe else 1)
         used = sum(nc for _, _, nc in plan_passes(self.k, n_groups, per)[0])
         return max(1, (MAX_ENGINE_COLS - used) // per)
 
@@ -562,6 +637,7 @@ class SketchRunner:
         nb, jl = self.plan.n_bin, self.j1 - self.j0
         self._check_missing = check_missing
         self._install_rhs(y)
+        self._span_ok = None          # decided per trait group: the passes (engines, columns) may differ from the last one's
         dev = self.device
         # The per-block sketches stay in HBM for pass 2 when they fit (C3: 2 GB, C4: 32 GB of the 288); otherwise pass 2
         # re-sketches every block like the reference's second pass and only one block's outputs are ever resident.  The
@@ -571,14 +647,15 @@ class SketchRunner:
         full = [(jl, nb, ns, self.n_pad) for ns, _ in shapes]
         old = getattr(self, "blocks_sk", None)
         if old is not None and not self.one_slot and [tuple(b.shape) for b in old] == full and \
-                [b.shape[2] for b in self.blocks_nm] == [nn for _, nn in shapes]:
+                [b.shape[2] for b in self.blocks_nm] == [nn for _, nn in shapes] and \
+                [b.shape[2] for b in self.blocks_cr] == list(self.pass_cross):
             for b in self.blocks_nm:
                 b.zero_()
             if self.dom:
                 for b in self.blocks_nmd:
                     b.zero_()
             return
-        self.blocks_sk = self.blocks_nm = self.blocks_skd = self.blocks_nmd = None
+        self.blocks_sk = self.blocks_nm = self.blocks_skd = self.blocks_nmd = self.blocks_cr = self.blocks_crd = None
         self.one_slot = bool(self.recompute_pass2)
         store_bytes = jl * nb * sum(ns for ns, _ in shapes) * self.n_pad * 4 * (2 if self.dom else 1)
         if not self.one_slot and dev.type == "cuda":
@@ -593,6 +670,9 @@ class SketchRunner:
         self.blocks_nm = [torch.zeros((max(jl, 1), nb, nn), dtype=torch.float64, device=dev) for _, nn in shapes]
         self.blocks_skd = [torch.empty_like(b) for b in self.blocks_sk] if self.dom else None
         self.blocks_nmd = [torch.zeros_like(b) for b in self.blocks_nm] if self.dom else None
+        # Gram matrices of the cross columns (the covariates): [block][bin][c][c] float64 -- all that is kept of XXUz
+        self.blocks_cr = [torch.zeros((max(jl, 1), nb, nx, nx), dtype=torch.float64, device=dev) for nx in self.pass_cross]
+        self.blocks_crd = [torch.zeros_like(b) for b in self.blocks_cr] if self.dom else None
 
     # ---- estimate-level views of one block's (or the total's) engine outputs ----------------------
     def _group(self, sk_list, name):
@@ -600,11 +680,43 @@ class SketchRunner:
         parts = [sk_list[p_][:, c0:c0 + nc] for p_, c0, _, nc in self.loc[name]]
         return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
-    def _block_estimates(self, sk_list, nm_list, skd_list=None, nmd_list=None):
+    def _cross_grams(self, cr_list, crd_list=None):
+        """S_a = W^T X_a X_a^T W ``[..., ne_g, c, c]`` of the genotype-derived estimates (G bins, then dominance or G x E
+        bins) from the per-pass Gram matrices of the cross columns ``[..., nbin, n_cross_p, n_cross_p]``."""
+        def grp(lst, name):
+            p_, o, c = self.cross_loc[name]
+            return lst[p_][..., o:o + c, o:o + c]
+        S = grp(cr_list, "W")
+        if self.dom:
+            S = torch.cat([S, grp(crd_list, "W")], dim=-3)
+        if self.n_gxe:
+            S = torch.cat([S, grp(cr_list, "eW")], dim=-3)
+        return S
+
+    def _pc_of(self, S):
+        """W^T XXUz_a[s] = S_a (Q W^T z_s) for every probe vector: ``[..., ne_g, c, c]`` -> ``[..., ne_g, k, c]``."""
+        return torch.einsum("...amn,ns->...asm", S, self.G64)
+
+    def _block_estimates(self, sk_list, nm_list, skd_list=None, nmd_list=None, cr_list=None, crd_list=None):
         """A = XXz, C = XXUz ``[ne_g, k, n_pad]`` and r = yXXy ``[ne_g, n_traits]`` of the genotype-derived estimates (G bins,
-        then dominance bins or G x E bins) from engine outputs of one block; float64."""
+        then dominance bins or G x E bins) from engine outputs of one block; float64.  With the covariates as cross columns
+        (``self.cross``) C is the projection ``W^T XXUz`` ``[ne_g, k, c]`` instead -- all the normal equations use of it."""
         f64 = torch.float64
         A = self._group(sk_list, "Z").to(f64)
+        if self.cov is not None and self.cross:
+            C = self._pc_of(self._cross_grams(cr_list, crd_list))
+            py, cy = self.loc["y"]
+            nt = self.n_traits
+            r = nm_list[py][:, cy:cy + nt]
+            if self.dom:
+                A = torch.cat([A, self._group(skd_list, "Z").to(f64)], dim=0)
+                r = torch.cat([r, nmd_list[py][:, cy:cy + nt]], dim=0)
+            if self.n_gxe:
+                gz = self._group(sk_list, "eZ")
+                A = torch.cat([A, (gz * self.env_pad.to(gz.dtype)).to(f64)], dim=0)
+                pe, ce = self.loc["ey"]
+                r = torch.cat([r, nm_list[pe][:, ce:ce + nt]], dim=0)
+            return A, C, r
         C = self._group(sk_list, "UZ").to(f64) if self.cov is not None else None
         py, cy = self.loc["y"]
         nt = self.n_traits
@@ -673,26 +785,31 @@ class SketchRunner:
             return {name: [lst[p_][:, c0:c0 + nc].contiguous() for p_, c0, _, nc in self.loc[name]]
                     for name in (("Z", "eZ") if self.n_gxe else ("Z",))}
 
-        tot_skd = tot_nmd = w_sk = w_skd = None
+        tot_skd = tot_nmd = w_sk = w_skd = tot_crd = None
         if not self.one_slot:
             self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0)
+            tot_cr = [b[:jl].sum(dim=0) for b in self.blocks_cr]
+            if self.dom:
+                tot_crd = [b[:jl].sum(dim=0) for b in self.blocks_crd]
             # Block sums as ONE float64 reduction over the stored per-block sketches per bucket (the reference adds the
             # blocks one by one in float64, base.py:468-471; any order agrees to 1e-16).  U is linear, so the "fixed" UXXz
             # total is U applied to the total (float32 rounding order differs from per-block application at 1e-7).
-            tot_sk = [reduce_async(self.eng.sum_blocks(b)) for b in self.blocks_sk]
+            sum_blocks = lambda b, *w_: (self.eng.sum_blocks(b, *w_) if b.shape[2] else      # a pass without sketch columns
+                                         torch.zeros(b.shape[1:], dtype=f64, device=dev))
+            tot_sk = [reduce_async(sum_blocks(b)) for b in self.blocks_sk]
             tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
             if self.dom:
-                tot_skd = [reduce_async(self.eng.sum_blocks(b)) for b in self.blocks_skd]
+                tot_skd = [reduce_async(sum_blocks(b)) for b in self.blocks_skd]
                 tot_nmd = [b[:jl].sum(dim=0) for b in self.blocks_nmd]
             if q4:
-                w_sk = z_part([self.eng.sum_blocks(b, w) for b in self.blocks_sk])
-                w_skd = z_part([self.eng.sum_blocks(b, w) for b in self.blocks_skd]) if self.dom else None
+                w_sk = z_part([sum_blocks(b, w) for b in self.blocks_sk])
+                w_skd = z_part([sum_blocks(b, w) for b in self.blocks_skd]) if self.dom else None
         else:
             # one-slot store: every block is added to the float64 totals (and the (jn - j)-weighted ones of quirk Q4)
             # right after its sketch, in block order
             zeros = lambda lst: [torch.zeros(b.shape[1:], dtype=f64, device=dev) for b in lst]
-            tot_sk, tot_nm = zeros(self.blocks_sk), zeros(self.blocks_nm)
-            tot_skd, tot_nmd = (zeros(self.blocks_skd), zeros(self.blocks_nmd)) if self.dom else (None, None)
+            tot_sk, tot_nm, tot_cr = zeros(self.blocks_sk), zeros(self.blocks_nm), zeros(self.blocks_cr)
+            tot_skd, tot_nmd, tot_crd = (zeros(self.blocks_skd), zeros(self.blocks_nmd), zeros(self.blocks_crd)) if self.dom else (None, None, None)
             wf = wfd = None
             if q4:
                 wf = zeros(self.blocks_sk)
@@ -702,9 +819,11 @@ class SketchRunner:
                 for p_ in range(self.n_pass):
                     tot_sk[p_] += self.blocks_sk[p_][0]
                     tot_nm[p_] += self.blocks_nm[p_][0]
+                    tot_cr[p_] += self.blocks_cr[p_][0]
                     if self.dom:
                         tot_skd[p_] += self.blocks_skd[p_][0]
                         tot_nmd[p_] += self.blocks_nmd[p_][0]
+                        tot_crd[p_] += self.blocks_crd[p_][0]
                     if q4:
                         wf[p_].add_(self.blocks_sk[p_][0], alpha=float(jn - j))
                         if self.dom:
@@ -719,7 +838,7 @@ class SketchRunner:
                 for chunks in (d_ or {}).values():
                     for t in chunks:
                         reduce_async(t)
-            small = tot_nm + (tot_nmd or [])                       # [nbin, n_norm] each: one packed buffer
+            small = tot_nm + (tot_nmd or []) + tot_cr + (tot_crd or [])     # [nbin, n_norm] / [nbin, c, c] each: one packed buffer
             flat = torch.cat([t.reshape(-1) for t in small])
             self._allreduce(flat)
             off = 0
@@ -728,7 +847,7 @@ class SketchRunner:
                 off += t.numel()
             for h in handles:
                 h.wait()
-        tot_A, tot_C, tot_r = self._block_estimates(tot_sk, tot_nm, tot_skd, tot_nmd)
+        tot_A, tot_C, tot_r = self._block_estimates(tot_sk, tot_nm, tot_skd, tot_nmd, tot_cr, tot_crd)
         tot_A, tot_r = tot_A.contiguous(), tot_r.clone()
         tot_C = tot_C.contiguous() if use_cov else None
         wsum = None
@@ -783,7 +902,7 @@ class SketchRunner:
             if use_cov:
                 tot_C, D_tot = tot_C.clone(), D_tot.clone()
                 tot_C[-1], D_tot[-1] = 0, 0
-                tot_C[-1, k - 1] = nxe[1][0, k - 1]
+                tot_C[-1, k - 1] = self._c_form(nxe[1][0, k - 1])
                 D_tot[-1, k - 1] = self._apply_U(nxe[0][0, k - 1], f32=True)
 
         def with_nxe(A, C, D, r):
@@ -792,8 +911,9 @@ class SketchRunner:
             A = torch.cat([A, nxe[0]], dim=0)
             r = torch.cat([r, nxe[2]], dim=0)
             if use_cov:
-                Cn = torch.zeros_like(nxe[0]); Dn = torch.zeros_like(nxe[0])
-                Cn[0, k - 1] = nxe[1][0, k - 1]
+                Dn = torch.zeros_like(nxe[0])
+                Cn = torch.zeros((1,) + tuple(C.shape[1:]), dtype=C.dtype, device=C.device)
+                Cn[0, k - 1] = self._c_form(nxe[1][0, k - 1])
                 Dn[0, k - 1] = self._apply_U(nxe[0][0, k - 1], f32=True)
                 C = torch.cat([C, Cn], dim=0)
                 D = torch.cat([D, Dn], dim=0)
@@ -814,14 +934,12 @@ class SketchRunner:
         if jn == 1 and js == [0]:                               # base.py:654-655: the only slot is the whole-data one
             js = []
         if js and not self.one_slot:
-            store = (self.blocks_sk, self.blocks_nm, self.blocks_skd, self.blocks_nmd)
+            store = (self.blocks_sk, self.blocks_nm, self.blocks_skd, self.blocks_nmd, self.blocks_cr, self.blocks_crd)
             Ts, qs = self._loo_systems(tots, nxe, store, len(js), M[js], yy)
             local = [(j, Ts[i], qs[i]) for i, j in enumerate(js)]
         else:
             for j in js:
-                sk, nm, skd, nmd = self._resketch(j)
-                store = ([t[None] for t in sk], [t[None] for t in nm],
-                         None if skd is None else [t[None] for t in skd], None if nmd is None else [t[None] for t in nmd])
+                store = tuple(None if lst is None else [t[None] for t in lst] for lst in self._resketch(j))
                 Ts, qs = self._loo_systems(tots, nxe, store, 1, M[j:j + 1], yy)
                 local.append((j, Ts[0], qs[0]))
         Ts, qs = self._loo_systems(tots, nxe, None, 1, M[jn:jn + 1], yy)
@@ -835,6 +953,10 @@ class SketchRunner:
         qs = np.stack([t[2] for t in local] + [q_tot])           # [jn+1, n_traits, ne+1]
         q_all = np.ascontiguousarray(np.transpose(qs, (1, 0, 2)))
         return Systems(Ts, q_all[0], M, q_all)
+
+    def _c_form(self, row: torch.Tensor) -> torch.Tensor:
+        """An explicit XXUz row ``[n_pad]`` in the form the C arrays are kept in: itself, or its projection W^T row ``[c]``."""
+        return self.WT64 @ row if self.cross else row
 
     def _pass2_torch(self, M, yy, tot_A, tot_C, D_tot, tot_r, nxe, with_nxe):
         """The same systems from materialised leave-one-out arrays and torch reductions: slow (degenerate GEMM shapes),
@@ -1014,13 +1136,14 @@ class SketchRunner:
         if self.n_nxe:
             nA = nxe[0][0]
             if use_cov:      # only the last probe vector carries XXUz / UXXz (base.py:472-481, see pass2)
-                nC = torch.zeros_like(nxe[0][0]); nD = torch.zeros_like(nxe[0][0])
-                nC[k - 1] = nxe[1][0, k - 1]
+                nD = torch.zeros_like(nxe[0][0])
+                nC = torch.zeros((k, self.cov.shape[1]) if self.cross else nD.shape, dtype=f64, device=dev)
+                nC[k - 1] = self._c_form(nxe[1][0, k - 1])
                 nD[k - 1] = self._apply_U(nxe[0][0, k - 1], f32=True)
         # Every inner product is a sum over probe columns: walk the column intervals on which each group sits in one
         # engine pass (a single interval unless num_random_vec exceeds what a pass holds) and add the pieces up.
         gram = tz = tk = gCD = None
-        PA_l, PbA_l, PC_l = [], [], []
+        PA_l, PbA_l, PC_l, PD_l = [], [], [], []
         if use_cov:
             Wr = [Row(self.WT64[m]) for m in range(self.WT64.shape[0])]
             c = len(Wr)
@@ -1045,8 +1168,15 @@ class SketchRunner:
                 tz = acc(tz, g[:, :, col]); col += 1
             if use_cov:
                 tk = acc(tk, g[:, :, col])
-                Cr = self._loo_rows(tot_C, store, "UZ", "eUZ", nC, s0, nc)
                 Dr = [Row(D_tot[a, s0:s0 + nc]) for a in range(D_tot.shape[0])] + ([Row(nD[s0:s0 + nc])] if nD is not None else [])
+                tA = self._dots(self._sub_rows(A_tot, nc), Wr, 1, 1).reshape(1, ne, nc, c)      # whole-data parts: once per pass
+                PA_l.append(tA + bA_flat); PbA_l.append(-bA_flat)
+                if self.cross:
+                    # XXUz is kept as W^T XXUz = S (Q W^T Z) only (see __init__); UXXz lies in span(W), so its products with
+                    # XXUz go through W^T UXXz (whole-data rows, once per pass 2)
+                    PD_l.append(self._dots(self._sub_rows(Dr, nc), Wr, 1, 1).reshape(1, ne, nc, c))
+                    continue
+                Cr = self._loo_rows(tot_C, store, "UZ", "eUZ", nC, s0, nc)
                 C_tot = [Row(r.tot) for r in Cr]
                 C_blk = [None if r.blk is None else Row(None, r.blk, r.mul, r.stride) for r in Cr]
                 # one pass over the stored XXUz rows: -<c_a, UXXz_b> and the projections -<c_a[s], W_m>
@@ -1055,16 +1185,27 @@ class SketchRunner:
                 # projections onto the covariates, P[z, a, s, m] = <row_a[s], W_m>; U = W Q W^T is applied through them:
                 # <U A_a, A_b> = sum_s PA[a,s] Q PA[b,s],  <C_a, U blkA_b> = sum_s PC[a,s] Q PblkA[b,s]  (base.py:583-593;
                 # UXXz_b = whole-data UXXz_b - U(block XXz_b), streaming_rhe.py:35-36)
-                tA = self._dots(self._sub_rows(A_tot, nc), Wr, 1, 1).reshape(1, ne, nc, c)      # whole-data parts: once per pass
                 tC = self._dots(self._sub_rows(C_tot, nc), Wr, 1, 1).reshape(1, ne, nc, c)
-                PA_l.append(tA + bA_flat); PbA_l.append(-bA_flat)
                 PC_l.append(tC + bC_flat)
         if use_cov:
-            PA, PbA, PC = (torch.cat(l, dim=2) if len(l) > 1 else l[0] for l in (PA_l, PbA_l, PC_l))
+            cat2 = lambda l: torch.cat(l, dim=2) if len(l) > 1 else l[0]
+            PA, PbA = cat2(PA_l), cat2(PbA_l)
             Q = self.Q64
-            flat = lambda P: P.reshape(batch, ne, k * c)
+            flat = lambda P: P.reshape(P.shape[0], ne, k * c)
             uaa = flat(PA @ Q) @ flat(PA).transpose(1, 2)
-            cd = gCD - flat(PC @ Q) @ flat(PbA).transpose(1, 2)
+            if self.cross:
+                PC = tot_C if nC is None else torch.cat([tot_C, nC[None]], dim=0)          # [ne, k, c] whole data
+                PC = PC[None]
+                if store is not None:
+                    blk = self._block_pc(store, batch)                                      # [batch, ne_g, k, c]
+                    if self.n_nxe:
+                        blk = torch.cat([blk, torch.zeros_like(blk[:, :1])], dim=1)
+                    PC = PC - blk
+                PD = cat2(PD_l)
+                cd = flat(PC @ Q) @ (flat(PD) - flat(PbA)).transpose(1, 2)      # <XXUz_a, UXXz_b - U blk XXz_b>
+            else:
+                PC = cat2(PC_l)
+                cd = gCD - flat(PC @ Q) @ flat(PbA).transpose(1, 2)
             gram = gram + cd - 2.0 * uaa
         # r = yXXy: whole-data minus block
         nt = self.n_traits
@@ -1114,11 +1255,17 @@ class SketchRunner:
         q[:, :, ne] = np.asarray(yy)[None, :]
         return T, q
 
+    def _block_pc(self, store, batch):
+        """W^T XXUz of ``batch`` stored blocks ``[batch, ne_g, k, c]`` from their cross Gram matrices."""
+        cr = [t[:batch] for t in store[4]]
+        crd = None if store[5] is None else [t[:batch] for t in store[5]]
+        return self._pc_of(self._cross_grams(cr, crd))
+
     def _stored_block(self, jl_i: int):
-        sk, nm = [b[jl_i] for b in self.blocks_sk], [b[jl_i] for b in self.blocks_nm]
+        sk, nm, cr = [b[jl_i] for b in self.blocks_sk], [b[jl_i] for b in self.blocks_nm], [b[jl_i] for b in self.blocks_cr]
         if self.dom:
-            return sk, nm, [b[jl_i] for b in self.blocks_skd], [b[jl_i] for b in self.blocks_nmd]
-        return sk, nm, None, None
+            return sk, nm, [b[jl_i] for b in self.blocks_skd], [b[jl_i] for b in self.blocks_nmd], cr, [b[jl_i] for b in self.blocks_crd]
+        return sk, nm, None, None, cr, None
 
     def _resketch(self, j: int):
         """Sketch block j again (the reference's pass 2 re-reads and re-imputes, base_streaming.py:110-118).  Blocks are
@@ -1134,11 +1281,15 @@ class SketchRunner:
         nm = [torch.empty((nb, max(e_.n_norm, 1)), dtype=torch.float64, device=dev) for e_ in self.engs[:self.n_pass]]
         skd = [torch.empty_like(t) for t in sk] if self.dom else None
         nmd = [torch.empty_like(t) for t in nm] if self.dom else None
+        cr = [torch.zeros((nb, nx, nx), dtype=torch.float64, device=dev) for nx in self.pass_cross]
+        crd = [torch.zeros_like(t) for t in cr] if self.dom else None
         for p in range(self.n_pass):
+            has_cr = self.pass_cross[p] > 0
             for i_, (a, b, ent, offs) in enumerate(pieces):
                 self._sketch_call(p, rows[a:b], ent, offs, None if fill is None else fill[a:b].contiguous(), sk[p], nm[p],
-                                  skd[p] if self.dom else None, nmd[p] if self.dom else None, accumulate=i_ > 0)
-        return sk, nm, skd, nmd
+                                  skd[p] if self.dom else None, nmd[p] if self.dom else None, accumulate=i_ > 0,
+                                  ocr=cr[p] if has_cr else None, ocrd=crd[p] if (has_cr and self.dom) else None)
+        return sk, nm, skd, nmd, cr, crd
 
     def _allreduce(self, t: torch.Tensor, async_op: bool = False):
         """Sum over the ranks, in place (RCCL over xGMI under the "nccl" backend); ``async_op``: returns the work handle."""
@@ -1174,7 +1325,11 @@ class SketchRunner:
         if use_cov:
             UA = self._apply_U(A, f32=False).reshape(ne, -1)
             t1 = (UA @ A2.T).cpu().numpy()                       # <U A_a, A_b>
-            t2 = (C.reshape(ne, -1) @ D.reshape(ne, -1).T).cpu().numpy()   # <XXUz_a, UXXz_b>
+            if self.cross:      # C = W^T XXUz [ne, k, c]; UXXz lies in span(W): <XXUz_a, UXXz_b> = sum_s (C_a[s] Q) . (W^T UXXz_b[s])
+                PD = D.reshape(ne, k, -1) @ self.W64
+                t2 = ((C @ self.Q64).reshape(ne, -1) @ PD.reshape(ne, -1).T).cpu().numpy()
+            else:
+                t2 = (C.reshape(ne, -1) @ D.reshape(ne, -1).T).cpu().numpy()   # <XXUz_a, UXXz_b>
             tk_all = (A2 @ self.UZ64.reshape(-1)).cpu().numpy()
         if self.genie_model is not None:
             tz_all = (A2 @ self.Z64.reshape(-1)).cpu().numpy()

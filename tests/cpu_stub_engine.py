@@ -23,9 +23,11 @@ class CpuStubEngine:
             k[list(missing)] = 0
         return k
 
-    def set_rhs(self, sketch_cols, norm_cols, keep):
+    def set_rhs(self, sketch_cols, norm_cols, keep, cross_cols=None):
         self.sk = None if sketch_cols is None else sketch_cols.double().numpy()
         self.nm = None if norm_cols is None else norm_cols.double().numpy()
+        self.cr = None if cross_cols is None else cross_cols.double().numpy()
+        self.n_cross = 0 if self.cr is None else self.cr.shape[0]
         self.keep = keep.numpy().astype(bool)
         self.n_sketch = 0 if self.sk is None else self.sk.shape[0]
         self.n_norm = 0 if self.nm is None else self.nm.shape[0]
@@ -36,7 +38,7 @@ class CpuStubEngine:
         return torch.from_numpy(g.sum(1).astype(np.int32)), torch.from_numpy((codes == 1).sum(1).astype(np.int32))
 
     def sketch_block(self, packed, entries, offsets, *, fill=None, out_sketch=None, out_norm=None, accumulate=False,
-                     want_colsum=False):
+                     want_colsum=False, out_cross=None):
         nbin = len(offsets) - 1
         if out_sketch is None:
             out_sketch = torch.zeros((nbin, self.n_sketch, self.n_pad), dtype=torch.float32)
@@ -59,6 +61,12 @@ class CpuStubEngine:
                     sk[:, self.keep] = (X @ (X.T @ self.sk[:, self.keep].T)).T
                 if self.n_norm:
                     nm[: self.n_norm] = ((X.T @ self.nm[:, self.keep].T) ** 2).sum(axis=0)
+                if self.n_cross:
+                    V = X.T @ self.cr[:, self.keep].T                                   # [m, c]
+                    S = torch.from_numpy(V.T @ V)
+                    out_cross[b] = out_cross[b] + S if accumulate else S
+            elif self.n_cross and not accumulate:
+                out_cross[b] = 0
             if accumulate:
                 out_sketch[b] += torch.from_numpy(sk).float()
                 out_norm[b] += torch.from_numpy(nm)

@@ -1,0 +1,70 @@
+"""Covariates as CROSS columns (W through the first contraction, S = W^T X X^T W per (block, bin) back) against the
+materialised U Z sketch columns, on the CPU stand-in engine: the two forms of the covariate terms of the normal equations
+(base.py:583-593: XXUz only enters through sum(XXUz * UXXz), UXXz lies in span(W), W^T X X^T (U Z) = S (Q W^T Z)) must give the
+same systems, for every model family the stand-in covers, in both UXXz semantics and with more probe vectors than a pass holds."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_golden, oracle_problem
+
+
+def _runner(name, materialize, compat, streaming):
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner, n_engines_needed
+    from tests.cpu_stub_engine import CpuStubEngine
+    z = load_golden(name)
+    p, c = oracle_problem(z)
+    plan = BlockPlan(c.annot, p.n_jack)
+    has_gxe = p.genie_model in ("G+GxE", "G+GxE+NxE")
+    engs = [CpuStubEngine(c.n_indv, p.n_indv) for _ in range(n_engines_needed(p.k, True, has_gxe))]
+    geno = torch.zeros((c.packed.shape[0], engs[0].pitch), dtype=torch.uint8)
+    geno[:, : c.packed.shape[1]] = torch.from_numpy(c.packed.copy())
+    env = None if p.genie_model is None else np.delete(np.asarray(p.env, np.float64).reshape(-1), p.missing_indv)
+    r = SketchRunner(engs, geno, plan, (0, p.n_jack), n_orig=c.n_indv, missing_indv=p.missing_indv, Z=p.Z, cov=p.cov,
+                     env=env, genie_model=p.genie_model, impute=p.impute, seed=p.seed, streaming=streaming, compat=compat,
+                     materialize_xxuz=materialize)
+    return r, p, z
+
+
+@pytest.mark.parametrize("name,compat,streaming", [("rhe_3bin_cov", "fixed", False), ("srhe_3bin_cov", "reference", True),
+                                                  ("rhe_2bin_cov_k35", "fixed", False), ("genie_gxe_cov", "reference", False),
+                                                  ("genie_gxe_nxe_cov", "reference", False), ("genie_gxe_cov", "fixed", True)])
+def test_cross_columns_give_the_systems_of_the_materialised_xxuz(name, compat, streaming):
+    rc, p, z = _runner(name, False, compat, streaming)
+    rm, _, _ = _runner(name, True, compat, streaming)
+    assert rc.cross and not rm.cross
+    sc = rc.run_trait(p.pheno[:, 0])
+    sm = rm.run_trait(p.pheno[:, 0])
+    assert "W" in rc.cross_loc and "UZ" not in rc.loc and "UZ" in rm.loc
+    assert np.array_equal(sc.M, sm.M)
+    scale = np.abs(sm.T).max(axis=(1, 2), keepdims=True)
+    assert np.abs(sc.T - sm.T).max() <= 1e-9 * scale.max(), np.abs((sc.T - sm.T) / scale).max()
+    assert np.allclose(sc.q, sm.q, rtol=1e-12, atol=0)
+    # the materialised cross-check path of pass 2 understands the projected form too
+    rc.pass2_impl = "torch"
+    st = rc.pass2()
+    assert np.abs(st.T - sm.T).max() <= 1e-9 * scale.max()
+
+
+def test_cross_gram_equals_projection_of_the_reference_xxuz_blocks():
+    """S_a (Q W^T z_b) per block against W^T applied to the REFERENCE's own per-block XXUz arrays."""
+    rc, p, z = _runner("rhe_3bin_cov", False, "fixed", False)
+    rc.run_trait(p.pheno[:, 0])
+    ref = z["ref_t0_XXUz_blocks"].astype(np.float64)                 # [ne, jn, k, N]
+    W = np.asarray(p.cov, np.float64)
+    for j in range(p.n_jack):
+        _, C, _ = rc._block_estimates(*rc._stored_block(j))          # [ne, k, c]
+        want = np.einsum("akn,nc->akc", ref[:, j], W)
+        assert np.abs(C.numpy() - want).max() <= 2e-6 * np.abs(want).max()
+
+
+def test_cross_columns_fall_back_when_they_do_not_pay():
+    from pyrhe_amd.streaming import cross_columns_pay, plan_passes
+    assert cross_columns_pay(10, 10, False) and cross_columns_pay(10, 19, False)
+    assert not cross_columns_pay(10, 20, False)        # a pass of their own against one pass with the U Z columns
+    assert not cross_columns_pay(10, 31, False)
+    assert cross_columns_pay(10, 10, True)             # two passes either way, the second one without a GEMM 2
+    passes, at = plan_passes(10, 2, 2, cross=[10, 10])
+    assert len(passes) == 2 and at == [(1, 0), (1, 10)] and passes[1] == []
+    passes, at = plan_passes(10, 1, 1, cross=[10])
+    assert len(passes) == 1 and at == [(0, 0)]

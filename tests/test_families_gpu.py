@@ -38,13 +38,20 @@ def _model(z, tmp_path, cls_name, **extra):
     return getattr(models, cls_name)(**kw)
 
 
+@pytest.mark.parametrize("materialize", [False, True])
 @pytest.mark.parametrize("name,cls", [("genie_gxe_2bin", "GENIE"), ("genie_gxe_cov", "GENIE"), ("genie_gxe_nxe_cov", "GENIE"),
                                       ("rhe_3bin_cov", "RHE"), ("rhe_dom_2bin", "RHE_DOM"), ("rhe_dom_cov", "RHE_DOM")])
-def test_block_sketches_of_every_family_vs_reference_blocks(name, cls, tmp_path):
+def test_block_sketches_of_every_family_vs_reference_blocks(name, cls, materialize, tmp_path):
+    """``materialize``: the U Z sketch columns as the reference has them (XXUz rows compared entry by entry); default: the
+    covariates as cross columns, XXUz kept as its projection W^T XXUz = S (Q W^T Z) [k, c] -- compared with W^T applied to
+    the reference's XXUz blocks (all that base.py:589-591 reads of them, since UXXz lies in span(W))."""
     z = load_golden(name)
-    m = _model(z, tmp_path, cls)
+    if materialize and "ref_t0_XXUz_blocks" not in z:
+        pytest.skip("no covariates: nothing to materialise")
+    m = _model(z, tmp_path, cls, materialize_xxuz=materialize)
     m(trait=0)
     r = m._runner
+    assert r.cov is None or r.cross == (not materialize)
     keep = r.keep_idx
     ref = z["ref_t0_XXz_blocks"].astype(np.float64)               # [ne, jn, k, N]
     refy = z["ref_t0_yXXy_blocks"]
@@ -70,8 +77,12 @@ def test_block_sketches_of_every_family_vs_reference_blocks(name, cls, tmp_path)
             refd = z["ref_t0_UXXz_blocks"].astype(np.float64)
             D = r._apply_U(A, f32=True)                            # pyrhe_engine_apply_projector on the block's XXz
             for a in range(ne_g):
-                sc = np.abs(refc[a, j]).max()
-                assert np.abs(C[a].cpu().numpy()[:, keep] - refc[a, j]).max() <= BLOCK_TOL * sc, ("XXUz", name, a, j)
+                if r.cross:
+                    want = refc[a, j] @ np.asarray(r.cov, np.float64)                   # [k, c]
+                    assert np.abs(C[a].cpu().numpy() - want).max() <= BLOCK_TOL * np.abs(want).max(), ("W^T XXUz", name, a, j)
+                else:
+                    sc = np.abs(refc[a, j]).max()
+                    assert np.abs(C[a].cpu().numpy()[:, keep] - refc[a, j]).max() <= BLOCK_TOL * sc, ("XXUz", name, a, j)
                 sd = np.abs(refd[a, j]).max()
                 assert np.abs(D[a].cpu().numpy()[:, keep] - refd[a, j]).max() <= BLOCK_TOL * sd, ("UXXz", name, a, j)
     print(f"[{name}] worst block deviation {worst:.2e} of the block maximum")

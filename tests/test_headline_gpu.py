@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 SEED = 20251212          # bench.py's SYNTH_SEED
 
 
-def _setup(n, m, jn, k, nbin=1, n_cov=0, row0=0):
+def _setup(n, m, jn, k, nbin=1, n_cov=0, row0=0, materialize=False, genie=None):
     from pyrhe_amd import engine
     from pyrhe_amd.streaming import BlockPlan, SketchRunner, engine_capacity, n_engines_needed
     dev = torch.device("cuda", 0)
@@ -41,16 +41,21 @@ def _setup(n, m, jn, k, nbin=1, n_cov=0, row0=0):
     cov = None
     if n_cov:
         cov = np.concatenate([np.ones((n, 1)), np.random.default_rng(2).normal(size=(n, n_cov - 1))], axis=1)
-    p = O.Problem(packed=plink.encode_bed_rows(g), n_indv_orig=n, annot=annot, pheno=y.reshape(-1, 1), n_jack=jn, k=k, seed=0, cov=cov)
+    env = None
+    kw = {}
+    if genie:
+        env = np.random.default_rng(3).integers(0, 2, n).astype(np.float64)      # Bernoulli(0.5), SURVEY 8d's config 5
+        kw = dict(env=env.reshape(-1, 1), genie_model=genie, compat="fixed")
+    p = O.Problem(packed=plink.encode_bed_rows(g), n_indv_orig=n, annot=annot, pheno=y.reshape(-1, 1), n_jack=jn, k=k, seed=0, cov=cov, **kw)
     p.Z = O.make_probe_vectors(0, n, k)
     plan = BlockPlan(annot, jn)
     engs = []
-    for _ in range(n_engines_needed(k, cov is not None, False)):
+    for _ in range(n_engines_needed(k, cov is not None, bool(genie))):
         e_ = engine.SketchEngine(n, n, max_entries=engine_capacity(plan), precision="i8x3", device=dev, sub_snps=engine_capacity(plan))
         e_.set_coding("value")
         engs.append(e_)
-    runner = SketchRunner(engs, geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=p.Z, cov=cov, seed=0, streaming=False,
-                          compat="fixed")
+    runner = SketchRunner(engs, geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=p.Z, cov=cov, seed=0, streaming=bool(genie),
+                          compat="fixed", materialize_xxuz=materialize, env=env, genie_model=genie)
     return p, runner, engs
 
 
@@ -78,6 +83,11 @@ def _check(p, runner, engs, want_path, blocks_per_call):
     finally:
         O.ACCUM = "reference"
     use_cov = p.cov is not None
+    ne_g = nb * (2 if p.genie_model else 1)                  # G bins, then G x E bins
+    W = None if not use_cov else np.asarray(p.cov, np.float64)
+    # covariates as cross columns (the default): the engine returns S = W^T X X^T W, the runner keeps XXUz as its projection
+    # W^T XXUz = S (Q W^T Z) [k, c] -- all the normal equations read of it (base.py:589-591); compared with W^T of the oracle's
+    proj = (lambda a: a @ W) if (use_cov and runner.cross) else (lambda a: a)
     worst = {}
 
     def compare(what, got, ref, exact):
@@ -92,12 +102,13 @@ def _check(p, runner, engs, want_path, blocks_per_call):
     for j in range(jn):
         A, C, r = runner._block_estimates(*runner._stored_block(j))
         blk, blx = st.blocks[j], st_x.blocks[j]
-        for b in range(nb):
+        for b in range(ne_g):
             checks.append(compare(("XXz", j, b), A[b, :, :N].cpu().numpy(), blk.XXz[b], blx.XXz[b]))
             assert abs(float(r[b, 0]) - blk.yXXy[b]) <= 1e-5 * abs(blk.yXXy[b]), ("yXXy", j, b)
             assert abs(float(r[b, 0]) - blx.yXXy[b]) <= 2e-6 * abs(blx.yXXy[b]), ("yXXy vs exact", j, b)
             if use_cov:
-                checks.append(compare(("XXUz", j, b), C[b, :, :N].cpu().numpy(), blk.XXUz[b], blx.XXUz[b]))
+                got = C[b].cpu().numpy() if runner.cross else C[b, :, :N].cpu().numpy()
+                checks.append(compare(("XXUz", j, b), got, proj(blk.XXUz[b]), proj(blx.XXUz[b])))
         assert not A[:, :, N:].any()
     for name, w in worst.items():
         print(f"[N={N}, {nb} bins] {name}: worst deviation of the block maximum -- engine vs exact sum {w[0]:.1e}, engine vs reference order "
@@ -117,11 +128,13 @@ def _check(p, runner, engs, want_path, blocks_per_call):
     sysm = runner.pass2()
     sig = est.solve_all(sysm.T, sysm.q)
     se = np.asarray(est.jackknife_se(sig[:-1], jn))
-    ref = O.rhe_results(p, st)
+    ref = O.genie_results(p, st) if p.genie_model else O.rhe_results(p, st)
     assert np.array_equal(sysm.M, st.M)
     # 1e-5 relative per entry; a component below 5 % of the largest one (a bin whose sigma^2 is statistically zero) is
     # judged against 5 % of the largest instead of against itself
-    floor = lambda v: np.maximum(np.abs(v), 0.05 * np.abs(v).max())
+    # (GENIE: 1e-5 of the largest component, the bound of tests/test_families_gpu.py -- its normal equations amplify the
+    # reference's own float32 accumulation noise 100x more than RHE's, tests/helpers.py:accumulation_noise_floor)
+    floor = (lambda v: np.full(np.shape(v), np.abs(v).max())) if p.genie_model else (lambda v: np.maximum(np.abs(v), 0.05 * np.abs(v).max()))
     rel = np.abs(sig[-1] - ref["sigma_ests_total"]) / floor(ref["sigma_ests_total"])
     rel_se = np.abs(se - ref["sig_errs"]) / floor(ref["sig_errs"])
     print(f"[N={N}, {nb} bins] sigma^2 rel {rel.max():.1e}, SE rel {rel_se.max():.1e}")
@@ -162,11 +175,39 @@ def test_headline_kernels_at_n50k_wide_gemm1_vs_oracle():
 
 
 def test_c4_shape_8bins_covariates_at_n200k_vs_oracle():
-    """BASELINE config 4's shape (8 bins + 10 covariates incl. the intercept): 21 right-hand columns = 64 packed digit rows =
-    the four-tile int8 GEMM 1, 20 sketch columns = the two-column-group packed int8 GEMM 2; XXz, XXUz and yXXy per block."""
+    """BASELINE config 4's shape (8 bins + 10 covariates incl. the intercept), covariates as CROSS columns (the default): 10
+    probes + phenotype + 10 covariates = 21 right-hand columns = 64 packed digit rows = the four-tile int8 GEMM 1; 10 sketch
+    columns = the ONE-column-group packed int8 GEMM 2; XXz, yXXy and the projection W^T XXUz = S (Q W^T Z) per block."""
     p, runner, engs = _setup(200_000, 1200, 3, 10, nbin=8, n_cov=10, row0=5)
+    assert runner.cross
+    # 24 lists per call (3 blocks x 8 bins of 50 SNPs): three lists share a workgroup of the packed GEMM 2 (PYRHE_OPT_G2_MERGE)
+    _check(p, runner, engs, {"gemm1": 104, "gemm2": 11, "segmented": True, "g2_merged": 3}, blocks_per_call=3)
+
+
+def test_c4_shape_materialised_xxuz_at_n200k_vs_oracle():
+    """The same shape with the U Z sketch columns materialised (`materialize_xxuz`: the reference's own XXUz arrays, what
+    covariate sets too wide for cross columns run): 20 sketch columns = the two-column-group packed int8 GEMM 2."""
+    p, runner, engs = _setup(200_000, 1200, 3, 10, nbin=8, n_cov=10, row0=5, materialize=True)
+    assert not runner.cross
     # 24 lists per call (3 blocks x 8 bins of 50 SNPs): six lists share a workgroup of the packed GEMM 2 (PYRHE_OPT_G2_MERGE)
     _check(p, runner, engs, {"gemm1": 104, "gemm2": 12, "segmented": True, "g2_merged": 6}, blocks_per_call=3)
+
+
+def test_c4_8bins_covariates_at_n500k_vs_oracle():
+    """BASELINE config 4 at ITS cohort size, N = 500 000: 8 bins + 10 covariates, three blocks of 240 SNPs (30 per list) in one
+    call -- the kernels bench.py --n-bin 8 --n-cov 10 times (four-tile GEMM 1, one-group packed GEMM 2 with merged lists)."""
+    p, runner, engs = _setup(500_000, 720, 3, 10, nbin=8, n_cov=10, row0=11)
+    _check(p, runner, engs, {"gemm1": 104, "gemm2": 11, "segmented": True}, blocks_per_call=3)
+
+
+def test_c5_streaming_genie_gxe_at_n500k_vs_oracle():
+    """BASELINE config 5 at its cohort size: StreamingGENIE("G+GxE"), N = 500 000, one Bernoulli environment, three blocks of
+    200 SNPs in one call -- Z and e.Z = 20 sketch columns + y, e.y = 22 right-hand columns = 67 digit rows = the FIVE-tile
+    int8 GEMM 1 and the two-column-group packed GEMM 2, unmerged (one list per block); per-block X X^T z, e.(X X^T (e.z)),
+    both norms, sigma^2 and SE against the oracle's definition of the model (Problem.compat = "fixed", streaming_genie.py:33-49)."""
+    p, runner, engs = _setup(500_000, 600, 3, 10, row0=23, genie="G+GxE")
+    assert not runner.quirk_last_total and runner.n_est == 2
+    _check(p, runner, engs, {"gemm1": 105, "gemm2": 12, "segmented": True, "g2_merged": 1}, blocks_per_call=3)
 
 
 def test_blocks_beyond_one_call_are_split_into_row_pieces():
@@ -227,19 +268,36 @@ def test_projector_kernel_vs_oracle_float32_chain():
     eng.close()
 
 
-@pytest.mark.parametrize("nbin,n_cov,with_missing", [(1, 0, False), (8, 10, False), (2, 0, True)])
-def test_calls_beyond_4gb_of_rows_equal_three_block_calls(nbin, n_cov, with_missing):
+@pytest.mark.parametrize("nbin,n_cov,with_missing,materialize", [(1, 0, False, False), (8, 10, False, False), (8, 10, False, True),
+                                                                 (2, 0, True, False)])
+def test_calls_beyond_4gb_of_rows_equal_three_block_calls(nbin, n_cov, with_missing, materialize):
     """PYRHE_OPT_LIST_SPAN: at N = 500k a call of more than 34 308 rows passes the 32-bit row offsets; the packed int8
-    GEMM 2 addresses every list relative to its own lowest row, so the runner batches by entries alone (GEMM 1 pays a fixed
-    cost per launch).  Four 10 000-SNP blocks (5 GB of rows) in ONE call against the same blocks at three per call:
+    GEMM 2 addresses the lists of a workgroup relative to their lowest row, so the runner batches by entries alone (GEMM 1 pays
+    a fixed cost per launch).  Four 10 000-SNP blocks (5 GB of rows) in ONE call against the same blocks at three per call:
     the per-block sketches are the same bits (exact int32 accumulation, per-list float32 epilogue)."""
+    outs = _span_runs(500_000, 40_000, 4, nbin, n_cov, with_missing, materialize, (None, 34_000), (4, 3), 65536)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_merged_lists_never_straddle_blocks_in_calls_beyond_4gb():
+    """Blocks of 18 000 SNPs at N = 500k (2.25 GB each): ONE block fits the 32-bit row span, TWO do not.  Lists that share a
+    workgroup of the packed GEMM 2 are addressed from their common lowest row, so in a two-block call the engine must never
+    merge the last bins of block 0 with the first of block 1 (round 2's grouping did: offsets wrapped, wrong rows, silently
+    wrong sketches).  Against the same blocks one per call."""
+    outs = _span_runs(500_000, 36_000, 2, 8, 10, False, False, (None, 34_000), (2, 1), 65536)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def _span_runs(N, M, jn, nbin, n_cov, with_missing, materialize, limits, want_blocks_per_call, cap):
     from pyrhe_amd import engine
     from pyrhe_amd.streaming import BlockPlan, SketchRunner
     dev = torch.device("cuda", 0)
-    N, M, jn, k = 500_000, 40_000, 4, 10
+    k = 10
     outs = []
-    for limit in (None, 34_000):
-        eng = engine.SketchEngine(N, N, max_entries=65536, precision="i8x3", device=dev, sub_snps=65536)
+    for limit, want_b in zip(limits, want_blocks_per_call):
+        eng = engine.SketchEngine(N, N, max_entries=cap, precision="i8x3", device=dev, sub_snps=cap)
         geno = engine.synth_genotypes(M, N, 31, 0, dev)
         if with_missing:                           # missing calls in every block: the kernels' fill path (row | fill << 24 lists)
             rows_m = torch.as_tensor(np.random.default_rng(3).choice(M, 500, replace=False), device=dev)
@@ -251,23 +309,23 @@ def test_calls_beyond_4gb_of_rows_equal_three_block_calls(nbin, n_cov, with_miss
         plan = BlockPlan(annot, jn)
         Z = np.random.default_rng(5).standard_normal((N, k)).astype(np.float32)
         cov = None
-        if n_cov:                                  # 8 bins + covariates: 20 sketch columns, merged segments, four-tile GEMM 1
+        if n_cov:                                  # 8 bins + covariates: merged segments, four-tile GEMM 1
             cov = np.random.default_rng(7).standard_normal((N, n_cov))
             cov[:, 0] = 1.0
         runner = SketchRunner([eng], geno, plan, (0, jn), n_orig=N, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True,
-                              compat="fixed" if n_cov else "reference")
+                              compat="fixed" if n_cov else "reference", materialize_xxuz=materialize)
         runner.row_limit = limit
         y = np.random.default_rng(6).standard_normal(N)
         runner.begin_trait(y - y.mean(), check_missing=with_missing)
-        assert runner._blocks_per_call() == (6 if limit is None else 3)
+        assert min(runner._blocks_per_call(), jn) == want_b
         runner.pass1()
         torch.cuda.synchronize()
         path = eng.last_path()
-        assert path["gemm2"] == (12 if n_cov else 11) and path["segmented"]
+        assert path["gemm2"] == (12 if (n_cov and materialize) else 11) and path["segmented"]
         assert (path["g2_merged"] > 1) == (nbin == 8)        # 5000-entry lists with 10 columns: two of them do not fit the LDS
-        outs.append([t.clone() for t in runner.blocks_sk[0][:jn]] + [runner.blocks_nm[0][:jn].clone()])
+        outs.append([t.clone() for t in runner.blocks_sk[0][:jn]] + [runner.blocks_nm[0][:jn].clone()] +
+                    [t[:jn].clone() for t in runner.blocks_cr if t.shape[2]])
         eng.close()
         del runner, geno
         torch.cuda.empty_cache()
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    return outs
