@@ -68,6 +68,14 @@ extern "C" {
                                normal equations need of XXUz = X X^T (U Z) (a9): it only enters through sum(XXUz * UXXz)
                                (base.py:589-591), UXXz lies in span(W), and W^T X X^T (U Z) = (W^T X X^T W)(Q W^T Z).     */
 
+/* role[c] | PYRHE_COL_DIGITS(d), d = 1, 2 (3 = default): the int8 modes feed this NORM / CROSS column to the first
+   contraction as its d most significant balanced radix-256 digits (8 d bits of its largest entry) instead of all three --
+   fewer packed digit rows, fewer 16-row tiles of matrix work and operand traffic.  Digit counts must not grow with the column
+   index; sketch columns always carry three.  For covariates as cross columns (their Gram matrix only enters the O(c / N)
+   terms of the normal equations) one digit moves sigma^2 by 2e-7 and the jackknife SE by 2e-6 at N = 2 000 and by 1 / N^2
+   beyond, two digits by 5e-8 at N = 500.  Ignored by the fp16 modes. */
+#define PYRHE_COL_DIGITS(d) ((d) << 8)
+
 #define PYRHE_MAX_COLS 30   /* sketch + norm + cross columns (a ones column is appended internally) */
 
 typedef struct pyrhe_engine pyrhe_engine_t;
@@ -270,7 +278,8 @@ int pyrhe_decode_rows(const uint8_t* packed, int64_t n_rows, int64_t pitch, floa
 int pyrhe_synth_genotypes(uint8_t* packed, int64_t n_rows, int64_t pitch, int64_t n_samples,
                           uint64_t seed, int64_t row0, void* stream);
 
-/* engine introspection: 0 n_pad, 1 sub_snps, 2 n_tiles_in, 3 n_sketch, 4 n_norm, 5 workspace bytes, 10 n_cross;
+/* engine introspection: 0 n_pad, 1 sub_snps, 2 n_tiles_in, 3 n_sketch, 4 n_norm, 5 workspace bytes, 10 n_cross,
+ * 11 packed (digit, column) rows of the int8 GEMM 1's operand;
  * which kernels the LAST sketch call launched (so a parity test can assert the path it checked is the path it meant):
  *   6 GEMM 1: 100 + tiles for gemm1_i8_kernel<tiles>, 200 + tiles for gemm1_i8w_kernel<tiles>, tiles for gemm1_kernel<tiles>
  *             (fp16), 0 before any call

@@ -99,6 +99,19 @@ __device__ __forceinline__ float i8p_scale(float maxabs) {
     if (!(maxabs > 0.0f) || !isfinite(maxabs)) return 1.0f;
     return 126.0f / maxabs;
 }
+// the first `nd` digits of x rounded to nearest (nd = 3: all of x): x ~ a1 + a2 / 256 [+ a3 / 65536]
+__device__ __forceinline__ void i8p_digits_n(float x, int nd, float& a1, float& a2, float& a3) {
+    a1 = rintf(x);
+    a2 = a3 = 0.0f;
+    if (nd == 1) return;
+    const float r1 = (x - a1) * 256.0f;               // [-128, 128]
+    a2 = rintf(r1);
+    if (nd == 3) {
+        a3 = rintf((r1 - a2) * 256.0f);               // [-128, 128]
+        if (a3 > 127.0f) { a3 -= 256.0f; a2 += 1.0f; }
+    }
+    if (a2 > 127.0f) { a2 -= 256.0f; a1 += 1.0f; }     // |a1| <= 127 since |x| <= 126
+}
 __device__ __forceinline__ void i8p_digits(float x, float& a1, float& a2, float& a3) {
     a1 = rintf(x);
     const float r1 = (x - a1) * 256.0f;               // [-128, 128]
@@ -108,15 +121,19 @@ __device__ __forceinline__ void i8p_digits(float x, float& a1, float& a2, float&
     if (a2 > 127.0f) { a2 -= 256.0f; a1 += 1.0f; }     // |a1| <= 127 since |x| <= 126
 }
 // Rows ("slots") of the int8 GEMM 1's B operand: the (digit, column) pairs packed densely into 16-row tiles instead of
-// one tile set per digit.  `ones` user columns carry three digits, the ones column (index `ones`, values 0 / 1) one:
-// slots 0..ones = digit 0 of every column, then digit 1 and digit 2 of the user columns; 3 * ones + 1 slots in all
-// (k = 10 probes + phenotype: 34 -> 3 tiles; with covariates or GxE, 21 columns: 64 -> 4 tiles instead of 6).
-__device__ __host__ __forceinline__ int i8_slot(int digit, int c, int ones) {
-    return digit == 0 ? c : (digit == 1 ? ones + 1 + c : 2 * ones + 1 + c);
+// one tile set per digit.  The `ones` user columns carry up to three digits -- the first nd3 of them three, the first
+// nd2 >= nd3 at least two, the rest one (the digit counts do not grow with the column index: sketch columns and
+// phenotypes keep all 24 bits, cross columns may carry fewer, PYRHE_COL_DIGITS) -- and the ones column (index `ones`,
+// values 0 / 1) one: slots 0..ones = digit 0 of every column, then digit 1 of columns 0..nd2-1, then digit 2 of columns
+// 0..nd3-1; ones + 1 + nd2 + nd3 slots in all (k = 10 probes + phenotype: 34 -> 3 tiles; with G x E, 22 columns: 67 -> 5 tiles
+// instead of 6; with 10 covariates as one-digit cross columns: 44 -> 3 tiles).
+__device__ __host__ __forceinline__ int i8_slot(int digit, int c, int ones, int nd2) {
+    return digit == 0 ? c : (digit == 1 ? ones + 1 + c : ones + 1 + nd2 + c);
 }
-__device__ __forceinline__ double i8_value(const int* __restrict__ Prow, int c, int ones) {
+__device__ __forceinline__ double i8_value(const int* __restrict__ Prow, int c, int ones, int nd2, int nd3) {
     double v = (double)Prow[c];
-    if (c < ones) v += (double)Prow[ones + 1 + c] * (1.0 / 256.0) + (double)Prow[2 * ones + 1 + c] * (1.0 / 65536.0);
+    if (c < nd2) v += (double)Prow[ones + 1 + c] * (1.0 / 256.0);
+    if (c < nd3) v += (double)Prow[ones + 1 + nd2 + c] * (1.0 / 65536.0);
     return v;
 }
 

@@ -84,6 +84,7 @@ struct pyrhe_engine {
     bool i8 = false;      // int8 digit kernels (precision i8x3: GEMM 1 always, GEMM 2 where the packed kernel applies)
     bool vc = false;      // the caller's packed buffers hold the 2-bit VALUE code (pyrhe_recode_rows), not PLINK codes
     int n_sketch = 0, n_norm = 0, n_cross = 0, n_user = 0, ntl = 0, nto = 0, nt8 = 0;
+    int nd2 = 0, nd3 = 0, nslots = 0;   // int8 GEMM 1: columns with >= 2 / 3 digits, packed (digit, column) rows (i8_slot)
     bool rhs_set = false;
     // device buffers
     half8* rfrag = nullptr;
@@ -318,6 +319,7 @@ extern "C" int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what) {
         case 8: return e->last_flow;
         case 9: return e->last_g2_merged;
         case 10: return e->n_cross;
+        case 11: return e->nslots;
         default: return -1;
     }
 }
@@ -326,15 +328,22 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
                                     const float* keep, void* stream_) {
     if (!e || !R || !role_host || !keep) return fail(PYRHE_EINVAL, "NULL argument");
     if (n_cols < 1 || n_cols > PYRHE_MAX_COLS) return fail(PYRHE_EINVAL, "n_cols %d outside 1..%d", n_cols, PYRHE_MAX_COLS);
-    int ns = 0, nn = 0, nx = 0;
+    int ns = 0, nn = 0, nx = 0, nd2 = 0, nd3 = 0, last_nd = 3;
     for (int c = 0; c < n_cols; ++c) {
-        if (role_host[c] == PYRHE_COL_SKETCH) {
+        const int nd = (role_host[c] >> 8) & 3 ? (role_host[c] >> 8) & 3 : 3;
+        if (nd > last_nd) return fail(PYRHE_EINVAL, "digit counts must not grow with the column index (column %d: %d after %d)", c, nd, last_nd);
+        last_nd = nd;
+        nd2 += nd >= 2;
+        nd3 += nd >= 3;
+        const int role = role_host[c] & 0xFF;
+        if (role == PYRHE_COL_SKETCH && nd != 3) return fail(PYRHE_EINVAL, "sketch columns carry all three digits (column %d)", c);
+        if (role == PYRHE_COL_SKETCH) {
             if (nn || nx) return fail(PYRHE_EINVAL, "sketch columns must precede norm and cross columns (column %d)", c);
             ++ns;
-        } else if (role_host[c] == PYRHE_COL_NORM) {
+        } else if (role == PYRHE_COL_NORM) {
             if (nx) return fail(PYRHE_EINVAL, "norm columns must precede cross columns (column %d)", c);
             ++nn;
-        } else if (role_host[c] == PYRHE_COL_CROSS) {
+        } else if (role == PYRHE_COL_CROSS) {
             ++nx;
         } else {
             return fail(PYRHE_EINVAL, "role[%d] = %d is not SKETCH/NORM/CROSS", c, role_host[c]);
@@ -351,7 +360,10 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
     e->n_cross = nx;
     e->n_user = n_cols;
     e->ntl = (n_cols + 1 + 15) / 16;
-    e->nt8 = (3 * n_cols + 1 + 15) / 16;          // int8 GEMM 1: tiles of packed (digit, column) rows, see i8_slot()
+    e->nd2 = nd2;
+    e->nd3 = nd3;
+    e->nslots = n_cols + 1 + nd2 + nd3;
+    e->nt8 = (e->nslots + 15) / 16;               // int8 GEMM 1: tiles of packed (digit, column) rows, see i8_slot()
     e->nto = ns ? (ns + 15) / 16 : 1;
     if (e->ntl > kMaxTiles) return fail(PYRHE_EINVAL, "too many columns");
     HIPCHK(hipMemcpyAsync(e->keep, keep, e->n_pad * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -366,7 +378,7 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
         const unsigned grid = (unsigned)((threads + 255) / 256);
         if (e->i8) {
             const int64_t th = (e->n_pad / 256) * 4 * e->nt8 * 64;
-            prep_rimg_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->nt8, e->colmax, e->rscale,
+            prep_rimg_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->nd2, e->nd3, e->nt8, e->colmax, e->rscale,
                                                                               (int4v*)e->rfrag, e->csum);
         } else if (e->parts == 2)
             prep_rfrag_kernel<2, true><<<grid, 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale, e->rfrag, e->csum);
@@ -575,7 +587,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         if (e->diag_g1_stats && gv != 2) { g1_diag |= 4; Pbuf2 = reinterpret_cast<float*>(e->diag_g1_stats); }   // bit 2: phase cycle account
 #endif
         e->last_g1 = e->i8 ? (wide ? 200 : 100) + e->nt8 : e->ntl;
-        const int live_last = e->opt_g1_zero_rows ? 3 * e->n_user + 1 - 16 * (e->nt8 - 1) : 16;     // live digit rows of the last int8 tile
+        const int live_last = e->opt_g1_zero_rows ? e->nslots - 16 * (e->nt8 - 1) : 16;     // live digit rows of the last int8 tile
         if (e->i8) {
             const size_t lds = (size_t)2 * g1_ch * 4 * e->nt8 * 1024;
 #define G1I(NT_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag, live_last); \
@@ -821,7 +833,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 ProfScope ps(e, stream, 1);
                 mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
                                                                  (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->vsq,
-                                                                 out_colsum ? out_colsum + chunk0 : nullptr, e->n_cross, e->vcross, tab);
+                                                                 out_colsum ? out_colsum + chunk0 : nullptr, e->n_cross, e->vcross, e->nd2, e->nd3, tab);
                 if (e->n_cross)
                     cross_reduce_kernel<<<tab.nseg * (e->n_cross * (e->n_cross + 1) / 2), 256, 0, stream>>>(e->vcross, e->n_cross, out_cross, tab);
             }
@@ -889,7 +901,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 ProfScope ps(e, stream, 1);
                 mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
                                                                  (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->vsq,
-                                                                 out_colsum ? out_colsum + offsets_host[b] + s0 : nullptr, e->n_cross, e->vcross, tab);
+                                                                 out_colsum ? out_colsum + offsets_host[b] + s0 : nullptr, e->n_cross, e->vcross, e->nd2, e->nd3, tab);
                 if (e->n_norm && !e->n_sketch) norm_reduce_kernel<<<e->n_norm, 256, 0, stream>>>(e->vsq, e->n_norm, normb, tab);
                 if (e->n_cross) cross_reduce_kernel<<<e->n_cross * (e->n_cross + 1) / 2, 256, 0, stream>>>(e->vcross, e->n_cross, crossb, tab);
             }
@@ -914,7 +926,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                     ProfScope ps(e, stream, 1);
                     mid_dom1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->P2, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale,
                                                                          e->csum, (float)e->n_keep, e->cmu, e->Wtmp, e->Wtmp2, e->wmax, e->wmax2,
-                                                                         e->vsq2, e->n_cross, e->vcross2);
+                                                                         e->vsq2, e->n_cross, e->vcross2, e->nd2, e->nd3);
                     if (e->n_norm && !e->n_sketch) norm_reduce_kernel<<<e->n_norm, 256, 0, stream>>>(e->vsq2, e->n_norm, normd, tab);
                     if (e->n_cross) cross_reduce_kernel<<<e->n_cross * (e->n_cross + 1) / 2, 256, 0, stream>>>(e->vcross2, e->n_cross, crossd, tab);
                 }

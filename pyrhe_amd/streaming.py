@@ -255,6 +255,11 @@ class SketchRunner:
                       cross_columns_pay(self.k, self.cov.shape[1], self.n_gxe > 0))
         if self.cross:
             self.G64 = torch.from_numpy(self.Q @ (self.cov.T @ self.Z)).to(self.device)      # [c, k]: U Z = W G
+            # int8 digits of the covariate columns in the first contraction (PYRHE_COL_DIGITS): S only enters the O(c / N) terms
+            # of T.  Measured on the CPU stand-in (N = 500 / 2000, 6 covariates, 3 bins): two digits move sigma^2 / SE by 4e-8 /
+            # 8e-8 at N = 500; ONE digit by 6e-6 / 1e-5 at N = 500, 2e-7 / 1.6e-6 at N = 2000 (it falls as 1 / N^2).  One digit
+            # packs 10 probes + phenotype + 10 covariates into 44 digit rows = three tiles (the 128-row GEMM 1) instead of four.
+            self.cross_digits = 1 if self.N >= 16384 else 2
         self.Z64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.Z.T)))        # [k, n_pad] f64
         if self.env is not None:
             self.env_pad = self._pad_cols(torch.from_numpy(self.env[None, :]))[0]            # [n_pad] f64
@@ -335,7 +340,8 @@ class SketchRunner:
             nm = torch.cat(norms, dim=0).to(torch.float32) if pi == 0 else None
             cr = [cgroups[i] for i, (cp, _) in enumerate(cross_at) if cp == pi]
             if cr:
-                self.engs[pi].set_rhs(sk, nm, self.keep, cross_cols=torch.cat(cr, dim=0).to(torch.float32))
+                self.engs[pi].set_rhs(sk, nm, self.keep, cross_cols=torch.cat(cr, dim=0).to(torch.float32),
+                                      cross_digits=self.cross_digits)
             else:
                 self.engs[pi].set_rhs(sk, nm, self.keep)
             self.pass_shapes.append((col, n_norm_all if pi == 0 else 0))
@@ -616,11 +622,17 @@ class SketchRunner:
         column (two with G x E), so the spare right-hand columns of the first engine pass carry further phenotypes for free
         (k = 10: 20 without covariates, 10 with; the reference re-runs everything per phenotype)."""
         per = 2 if self.n_gxe else 1
-        if self.cov is not None and self.cross:      # the cross columns that share pass 0 with one phenotype stay there
+        if self.cov is not None and self.cross:
+            # the covariate (cross) columns share the passes with the phenotypes: as many phenotypes as leave the plan within
+            # the engines at hand -- a few fit beside the cross columns in pass 0; more push the cross columns into a later pass
+            # where there is one (G x E + covariates: a pass of GEMM 1 alone, far cheaper than a second trait group)
             c = self.cov.shape[1]
-            passes, cross_at = plan_passes(self.k, per, per, cross=[c] * per)
-            used = sum(nc for _, _, nc in passes[0]) + sum(c for cp, _ in cross_at if cp == 0)
-            return max(1, (MAX_ENGINE_COLS - used) // per)
+            used = sum(nc for _, _, nc in plan_passes(self.k, per, per)[0])
+            best = 1
+            for nt in range(1, (MAX_ENGINE_COLS - used) // per + 1):
+                if len(plan_passes(self.k, per, per * nt, cross=[c] * per)[0]) <= len(self.engs):
+                    best = nt
+            return best
         n_groups = (2 if self.cov is not None else 1) * (2 if self.n_gxe else 1)
         used = sum(nc for _, _, nc in plan_passes(self.k, n_groups, per)[0])
         return max(1, (MAX_ENGINE_COLS - used) // per)

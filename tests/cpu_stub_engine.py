@@ -23,7 +23,7 @@ class CpuStubEngine:
             k[list(missing)] = 0
         return k
 
-    def set_rhs(self, sketch_cols, norm_cols, keep, cross_cols=None):
+    def set_rhs(self, sketch_cols, norm_cols, keep, cross_cols=None, cross_digits=3):
         self.sk = None if sketch_cols is None else sketch_cols.double().numpy()
         self.nm = None if norm_cols is None else norm_cols.double().numpy()
         self.cr = None if cross_cols is None else cross_cols.double().numpy()

@@ -609,3 +609,106 @@ def test_gemm1_launch_shape_options_do_not_change_a_bit(dev):
     for other in res[1:]:
         for a, b in zip(res[0], other):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision,digits", [("i8x3", 3), ("i8x3", 2), ("i8x3", 1), ("f16x2", 3)])
+@pytest.mark.parametrize("nbin,with_sketch", [(1, True), (3, True), (3, False)])
+def test_cross_columns_gram_vs_float64(dev, precision, digits, nbin, with_sketch):
+    """PYRHE_COL_CROSS through the C ABI (pyrhe_engine_sketch_block_cross): out_cross[b] = R_x^T X_b X_b^T R_x for the cross
+    columns R_x, against float64 arithmetic on the decoded genotypes standardized the reference's way (base.py:291-296) --
+    beside sketch and norm columns (whose outputs must not move), in both kernel flows (one list / several lists per call),
+    with cross columns alone (no second contraction), and fed with 3, 2 or 1 int8 digits (PYRHE_COL_DIGITS: 24, 16, 8 bits of
+    the column maximum; tolerance 2e-6 / 1e-4 / 2e-2 of the largest entry).  Accumulating calls add."""
+    from pyrhe_amd import engine
+    n, m, k, c = 1003, 330, 4, 5
+    g = synth.synth_rows(20251212, 77, m, n)
+    packed = engine.upload_packed(plink.encode_bed_rows(g), dev)
+    rng = np.random.default_rng(8)
+    Z = rng.standard_normal((k, n))
+    y = rng.standard_normal((1, n))
+    W = rng.standard_normal((c, n))
+    W[0] = 1.0                                                   # an intercept: X^T 1 = 0 up to the float32 mean
+    W[1] = rng.integers(0, 2, n)                                 # a binary covariate: exact in one digit
+    eng = engine.SketchEngine(n, n, max_entries=m, precision=precision, device=dev)
+    keep = eng.keep_vector([])
+    pad = lambda a: torch.nn.functional.pad(torch.from_numpy(a.astype(np.float32)), (0, eng.n_pad - n)).to(dev)
+    eng.set_rhs(pad(Z) if with_sketch else None, pad(y), keep, cross_cols=pad(W), cross_digits=digits)
+    assert eng.n_cross == c and int(eng.lib.pyrhe_engine_info(eng._h, 10)) == c
+    if precision == "i8x3":
+        ncol = (k if with_sketch else 0) + 1 + c
+        want_slots = ncol + 1 + (ncol - c if digits < 2 else ncol) + (ncol - c if digits < 3 else ncol)
+        assert int(eng.lib.pyrhe_engine_info(eng._h, 11)) == want_slots
+    lists = [np.sort(rng.choice(m, size=rng.integers(40, 200), replace=False)).astype(np.int32) for _ in range(nbin)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+    ent = torch.from_numpy(np.concatenate(lists)).to(dev)
+    out_cross = torch.full((nbin, c, c), 7.0, dtype=torch.float64, device=dev)          # overwritten, not added to
+    sk, nm, _ = eng.sketch_block(packed, ent, offs, out_cross=out_cross)
+    sk2, nm2, _ = eng.sketch_block(packed, ent, offs, out_sketch=sk.clone(), out_norm=nm.clone(), out_cross=out_cross, accumulate=True)
+    torch.cuda.synchronize()
+    tol = {3: 2e-6, 2: 1e-4, 1: 2e-2}[digits] if precision == "i8x3" else 5e-6
+    for b, rows in enumerate(lists):
+        G = g[rows].astype(np.float32)
+        mu = G.mean(axis=1, dtype=np.float32)
+        d = (np.float32(1) / np.sqrt(mu * (np.float32(1) - np.float32(0.5) * mu))).astype(np.float64)
+        X = (G.astype(np.float64) - mu[:, None].astype(np.float64)) * d[:, None]                    # [m_b, n]
+        V = X @ W.astype(np.float32).astype(np.float64).T                                            # [m_b, c]
+        S = V.T @ V
+        got = out_cross[b].cpu().numpy() / 2                                                        # two accumulated calls
+        assert np.abs(got - S).max() <= tol * np.abs(S).max(), (b, np.abs(got - S).max() / np.abs(S).max())
+        assert np.array_equal(got, got.T)
+        # exact covariates (the binary column, up to the intercept's zero) stay at float32 accuracy whatever the digit count
+        assert abs(got[1, 1] - S[1, 1]) <= 5e-6 * S[1, 1]
+        vy = X @ y[0].astype(np.float32).astype(np.float64)
+        assert abs(float(nm[b, 0]) - vy @ vy) <= 1e-5 * (vy @ vy)
+        if with_sketch:
+            ref = (X.T @ (X @ Z.astype(np.float32).astype(np.float64).T)).T                          # [k, n]
+            assert np.abs(sk[b, :, :n].double().cpu().numpy() - ref).max() <= (5e-6 if precision != "f16" else 2e-3) * np.abs(ref).max()
+    eng.close()
+
+
+def test_cross_columns_dominance_and_api_errors(dev):
+    """The dominance encoding's Gram matrix (RHE_DOM: X_dom of rhe_dom.py:15-41) through the same entry point, and the
+    argument checks of the cross API."""
+    from pyrhe_amd import engine
+    n, m, k, c = 900, 200, 3, 4
+    g = synth.synth_rows(20251212, 5, m, n)
+    packed = engine.upload_packed(plink.encode_bed_rows(g), dev)
+    rng = np.random.default_rng(9)
+    Z, y, W = rng.standard_normal((k, n)), rng.standard_normal((1, n)), rng.standard_normal((c, n))
+    eng = engine.SketchEngine(n, n, max_entries=m, precision="i8x3", device=dev)
+    keep = eng.keep_vector([])
+    pad = lambda a: torch.nn.functional.pad(torch.from_numpy(a.astype(np.float32)), (0, eng.n_pad - n)).to(dev)
+    eng.set_rhs(pad(Z), pad(y), keep, cross_cols=pad(W), cross_digits=3)
+    rows = np.arange(m, dtype=np.int32)
+    ent = torch.from_numpy(rows).to(dev)
+    cr = torch.zeros((1, c, c), dtype=torch.float64, device=dev)
+    crd = torch.zeros_like(cr)
+    eng.sketch_block_dom(packed, ent, [0, m], out_cross=cr, out_cross_dom=crd)
+    torch.cuda.synchronize()
+    G = g.astype(np.float64)
+    mu = G.mean(axis=1)
+    X = (G - mu[:, None]) / np.sqrt(mu * (1 - mu / 2))[:, None]
+    p_ = mu / 2
+    enc = np.where(G == 1, (2 * p_)[:, None], np.where(G == 2, (4 * p_ - 2)[:, None], 0.0))
+    Xd = (enc - enc.mean(axis=1, keepdims=True)) / (2 * p_ * (1 - p_))[:, None]
+    W64 = W.astype(np.float32).astype(np.float64)
+    for got, Xx in ((cr, X), (crd, Xd)):
+        V = Xx @ W64.T
+        S = V.T @ V
+        assert np.abs(got[0].cpu().numpy() - S).max() <= 5e-6 * np.abs(S).max()
+    # the plain entry points refuse an engine with cross columns; the cross entry point one without
+    with pytest.raises(engine.SketchError, match="out_cross"):
+        engine._check(eng.lib.pyrhe_engine_sketch_block(eng._h, packed.data_ptr(), m, ent.data_ptr(), (engine.C.c_int64 * 2)(0, m), 1, None,
+                                                        torch.empty((1, k, eng.n_pad), device=dev).data_ptr(),
+                                                        torch.empty((1, 1), dtype=torch.float64, device=dev).data_ptr(), None, 0, None), "sketch_block")
+    eng.set_rhs(pad(Z), pad(y), keep)
+    with pytest.raises(engine.SketchError, match="PYRHE_COL_CROSS"):
+        engine._check(eng.lib.pyrhe_engine_sketch_block_cross(eng._h, packed.data_ptr(), m, ent.data_ptr(), (engine.C.c_int64 * 2)(0, m), 1, None,
+                                                              None, None, cr.data_ptr(), None, None, None, 0, None), "sketch_block_cross")
+    # digit counts must not grow with the column index; sketch columns keep all three
+    roles = (engine.C.c_int32 * 3)(engine.COL_NORM | (2 << 8), engine.COL_CROSS | (3 << 8), engine.COL_CROSS | (1 << 8))
+    R = pad(rng.standard_normal((3, n)))
+    assert eng.lib.pyrhe_engine_set_rhs(eng._h, R.data_ptr(), roles, 3, keep.data_ptr(), None) == -1
+    roles = (engine.C.c_int32 * 2)(engine.COL_SKETCH | (2 << 8), engine.COL_NORM)
+    assert eng.lib.pyrhe_engine_set_rhs(eng._h, R.data_ptr(), roles, 2, keep.data_ptr(), None) == -1
+    eng.close()
