@@ -69,6 +69,12 @@ def parse_args():
     ap.add_argument("--materialize-xxuz", action="store_true",
                     help="covariates as the k sketch columns U Z (the reference's XXUz arrays) instead of c cross columns whose "
                          "Gram matrix W^T X X^T W replaces them (SketchRunner.cross)")
+    ap.add_argument("--compat", default=None, choices=["reference", "fixed"],
+                    help="UXXz semantics with covariates (SketchRunner compat); default: fixed with covariates / GENIE")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="rehearsal aid: initialise the process group and run every collective of the multi-GPU path (in-place "
+                         "float64 all-reduce per bucket, packed norm all-reduce, tensor all-gather of the systems, barriers) even "
+                         "with ONE rank -- RCCL then executes on a one-GPU box")
     ap.add_argument("--no-cross-check", action="store_true", help="skip the in-run i8x3 vs f16x2 comparison on three blocks")
     return ap.parse_args()
 
@@ -124,8 +130,12 @@ def main():
     # one GPU (local_rank wraps around), which RCCL refuses.
     backend = os.environ.get("PYRHE_DIST_BACKEND", "nccl")
     dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
-    if world > 1:
+    use_dist = world > 1 or args.force_collectives
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -210,14 +220,14 @@ def main():
     # engine's 30 right-hand columns go to further engines (k = 10: one, or two for GxE + covariates)
     n_eng = n_engines_needed(k, cov is not None, bool(args.genie))
     engines = [engine] + [make_engine(args.precision) for _ in range(n_eng - 1)]
-    compat = "fixed" if (cov is not None or args.genie) else "reference"
+    compat = args.compat or ("fixed" if (cov is not None or args.genie) else "reference")
     runner = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, env=env,
                           genie_model=args.genie, seed=0, streaming=True, dom=args.dom, compat=compat,
-                          materialize_xxuz=args.materialize_xxuz)
+                          materialize_xxuz=args.materialize_xxuz, force_collectives=args.force_collectives)
     runner.begin_trait(y, check_missing=check_missing)      # the generator itself emits no missing calls (contract of synth_kernel)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             if backend == "nccl":
                 dist.barrier(device_ids=[dev.index])
             else:
@@ -231,7 +241,7 @@ def main():
             rn.pass1()
         barrier()
         dt_ = time.perf_counter() - t0_
-        if world > 1:
+        if use_dist:
             t_ = torch.tensor([dt_], dtype=torch.float64, device=dev)
             dist.all_reduce(t_, op=dist.ReduceOp.MAX)
             dt_ = float(t_.item())
@@ -320,6 +330,14 @@ def main():
                       "covariates_as": None if cov is None else ("cross columns (W^T X X^T W per block and bin)" if runner.cross else "U Z sketch columns")},
            "roofline": roofline}
 
+    if use_dist:
+        # what the collectives saw: backend, ranks, blocks per rank (an all-gather of this rank's count)
+        mine = torch.tensor([j1 - j0], dtype=torch.int64, device=dev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        out["config"]["dist"] = {"backend": dist.get_backend(), "world": dist.get_world_size(),
+                                 "blocks_per_rank": [int(p_.item()) for p_ in parts], "collectives_forced": bool(args.force_collectives and world == 1)}
+
     def extra(name, fn):
         """A leg beside the headline: its failure is reported in the line, it never sinks the measured number."""
         try:
@@ -344,6 +362,33 @@ def main():
             out["config"]["sigma_total"] = [float(v) for v in sig[-1]]
             out["config"]["sigma_se"] = [float(v) for v in est.jackknife_se(sig[:-1], jn)]
     extra("end_to_end", leg_end_to_end)
+
+    def leg_plink_coded():
+        """The same pass on PLINK-coded rows (the .bed body as it is; the C ABI's default coding): what the one-time value-code
+        transcode buys per pass, and what it costs (timed here on this rank's rows; the product hides it behind the upload,
+        engine.upload_packed(recode="value"))."""
+        if coding != "value" or args.dom:
+            return
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng_mod.recode_rows(geno, "plink")
+        torch.cuda.synchronize()
+        t_rec = time.perf_counter() - t0
+        try:
+            for e_ in engines:
+                e_.set_coding("plink")
+            runner.pass1()
+            dt3 = timed_passes(runner)
+            out["config"]["plink_coded"] = {"value": M * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3,
+                                            "pass_frac": round(M * args.steps / dt3 * row_bytes / 1e9 / HBM_PEAK_GBS, 4)}
+            out["config"]["recode_ms"] = round(t_rec * 1e3, 2)
+        finally:
+            eng_mod.recode_rows(geno, "value")
+            for e_ in engines:
+                e_.set_coding("value")
+            torch.cuda.synchronize()
+    if not args.no_alt:
+        extra("plink_coded", leg_plink_coded)
 
     def leg_cross_check():
         """The kernels behind `value` against the fp16 hi+lo kernels (other code in every stage) on the first three local
@@ -437,7 +482,7 @@ def main():
         e_.close()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -126,11 +126,14 @@ def _require_gpu(device) -> torch.device:
     return device
 
 
-def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28) -> torch.Tensor:
+def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28, recode: Optional[str] = None) -> torch.Tensor:
     """Host ``[m, ceil(N/4)]`` uint8 rows (a NumPy array or a memory-mapped ``.bed`` body) -> device ``[m, pitch]``,
     zero padded.  The rows are never decoded on the host; they go through two pinned staging buffers of ``chunk_bytes``
     (the host-side copy of piece i+1 overlaps the transfer of piece i), so a memory-mapped 100-GB file needs neither
-    100 GB of RAM nor one giant copy."""
+    100 GB of RAM nor one giant copy.  ``recode="value"``: every piece is recoded in place to the 2-bit value code
+    (``pyrhe_recode_rows``) on a second stream as soon as it has landed, WHILE the next piece crosses PCIe -- the one-time
+    transcode (51 ms per 125 GB of kernel time) then costs the load nothing but the last piece's 0.1 ms, where a recode after
+    the upload cost a single-trait run (one sketch pass of 46 ms) more than the 2 ms per pass it saves."""
     device = _require_gpu(device)
     m, rb = packed_rows.shape
     pitch = (rb + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
@@ -141,6 +144,7 @@ def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28) -
     staging = [torch.empty((min(rows_per, m), rb), dtype=torch.uint8).pin_memory() for _ in range(2 if m > rows_per else 1)]
     done = [None, None]
     with torch.cuda.device(device):
+        side = torch.cuda.Stream(device) if recode else None
         for i, r0 in enumerate(range(0, m, rows_per)):
             r1 = min(r0 + rows_per, m)
             buf = staging[i % len(staging)]
@@ -151,7 +155,13 @@ def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28) -
             ev = torch.cuda.Event()
             ev.record()
             done[i % 2] = ev
+            if recode:
+                side.wait_event(ev)                           # the piece has landed (and `out` was zeroed before it)
+                with torch.cuda.stream(side):
+                    recode_rows(out[r0:r1], recode)
         torch.cuda.current_stream(device).synchronize()
+        if recode:
+            side.synchronize()
     return out
 
 

@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 from . import estimate as est
 from . import io as rio
-from .engine import SketchEngine, recode_rows, upload_packed
+from .engine import SketchEngine, upload_packed
 from .logger import Logger
 from .streaming import engine_capacity, n_engines_needed, BlockPlan, SketchRunner, shard_ranges
 
@@ -134,8 +134,9 @@ class Base:
         packed = rio.read_bed_packed(geno_file + ".bed", self.num_indv_original, self.num_snp)
         r0 = self.plan.range(j0)[0] if j1 > j0 else 0
         r1 = self.plan.range(j1 - 1)[1] if j1 > j0 else 0
-        self.geno_dev = upload_packed(packed[r0:r1], self.device)      # memmap slice -> HBM in pinned 1 GiB pieces
-        recode_rows(self.geno_dev, "value")                            # PLINK code -> allele counts, once, in place
+        # memmap slice -> HBM in pinned 256 MiB pieces; PLINK code -> allele counts in place, piece by piece on a second
+        # stream while the next piece crosses PCIe: the transcode is hidden behind the load it belongs to
+        self.geno_dev = upload_packed(packed[r0:r1], self.device, recode="value")
         self._sub_snps = sub_snps
         self.engine = self._new_engine()
         self._engines = [self.engine]

@@ -187,7 +187,8 @@ class SketchRunner:
                  env: Optional[np.ndarray] = None, genie_model: Optional[str] = None,
                  impute: str = "binary", seed: int = 0, streaming: bool = True, compat: str = "reference",
                  recompute_pass2: bool = False, rng_prefix_draws: int = 0, group=None, dom: bool = False,
-                 solo: bool = False, rng_prefix_high: int = 2, materialize_xxuz: bool = False):
+                 solo: bool = False, rng_prefix_high: int = 2, materialize_xxuz: bool = False,
+                 force_collectives: bool = False, cross_digits: Optional[int] = None):
         self.engs = list(engines) if isinstance(engines, (list, tuple)) else [engines]
         self.eng = self.engs[0]
         self.geno = geno
@@ -217,6 +218,9 @@ class SketchRunner:
         # solo: a runner over data every rank holds by itself (a cross-check beside a sharded job): no collectives
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized() and not solo) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # the cross-rank exchange of pass 1 / pass 2 runs when there is more than one rank -- or, for the one-GPU rehearsal of
+        # the RCCL path (tests/test_distributed_gpu.py), on a one-rank group when asked to
+        self.collective = self.world > 1 or bool(force_collectives and dist.is_available() and dist.is_initialized() and not solo)
         self.device = geno.device
         self.n_pad = self.eng.n_pad
         self.row0 = plan.range(self.j0)[0] if self.j1 > self.j0 else 0
@@ -257,9 +261,12 @@ class SketchRunner:
             self.G64 = torch.from_numpy(self.Q @ (self.cov.T @ self.Z)).to(self.device)      # [c, k]: U Z = W G
             # int8 digits of the covariate columns in the first contraction (PYRHE_COL_DIGITS): S only enters the O(c / N) terms
             # of T.  Measured on the CPU stand-in (N = 500 / 2000, 6 covariates, 3 bins): two digits move sigma^2 / SE by 4e-8 /
-            # 8e-8 at N = 500; ONE digit by 6e-6 / 1e-5 at N = 500, 2e-7 / 1.6e-6 at N = 2000 (it falls as 1 / N^2).  One digit
-            # packs 10 probes + phenotype + 10 covariates into 44 digit rows = three tiles (the 128-row GEMM 1) instead of four.
-            self.cross_digits = 1 if self.N >= 16384 else 2
+            # 8e-8 at N = 500; ONE digit by 6e-6 / 1e-5 at N = 500, 2e-7 / 1.6e-6 at N = 2000 (it falls as 1 / N^2: below 3e-8
+            # from N = 16 384 on).  One digit packs 10 probes + phenotype + 10 covariates into 44 digit rows = three tiles (the
+            # 128-row GEMM 1) instead of four: 8 bins + 10 covariates at N = 500k 30.5 -> 23.7 ms per pass in GEMM 1.  S itself
+            # then carries the 1 % quantisation noise of an 8-bit W (exact for an intercept or 0/1 covariates); small cohorts,
+            # where a tile more costs nothing, keep all three digits.  ``cross_digits`` overrides (tests hold S to 2e-5 at 3).
+            self.cross_digits = int(cross_digits) if cross_digits else (1 if self.N >= 16384 else 3)
         self.Z64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.Z.T)))        # [k, n_pad] f64
         if self.env is not None:
             self.env_pad = self._pad_cols(torch.from_numpy(self.env[None, :]))[0]            # [n_pad] f64
@@ -785,7 +792,7 @@ class SketchRunner:
         handles = []
 
         def reduce_async(t):
-            if self.world > 1:
+            if self.collective:
                 h = self._allreduce(t, async_op=True)
                 if h is not None:
                     handles.append(h)
@@ -845,7 +852,7 @@ class SketchRunner:
                 reduce_async(t)
             if q4:
                 w_sk, w_skd = z_part(wf), (z_part(wfd) if self.dom else None)
-        if self.world > 1:
+        if self.collective:
             for d_ in (w_sk, w_skd):
                 for chunks in (d_ or {}).values():
                     for t in chunks:
@@ -958,7 +965,7 @@ class SketchRunner:
         T_tot, q_tot = Ts[0], qs[0]
         if jn == 1 and self.j0 == 0 and self.j1 == 1:
             local = [(0, T_tot, q_tot)]
-        if self.world > 1:
+        if self.collective:
             local = self._gather_systems(local, T_tot.shape, q_tot.shape)
         local.sort(key=lambda t: t[0])
         Ts = np.stack([t[1] for t in local] + [T_tot])
@@ -990,7 +997,7 @@ class SketchRunner:
                 T, q = self._system(*with_nxe(tot_A - A, C, D, tot_r - r), M[j], yy)
             local.append((j, T, q))
         T_tot, q_tot = self._system(*with_nxe(tot_A, tot_C, D_tot, tot_r), M[jn], yy)
-        if self.world > 1:
+        if self.collective:
             local = self._gather_systems(local, T_tot.shape, q_tot.shape)
         local.sort(key=lambda t: t[0])
         return Systems(np.stack([t[1] for t in local] + [T_tot]), np.stack([t[2] for t in local] + [q_tot]), M)

@@ -39,6 +39,7 @@ def test_bench_two_ranks_equal_one_rank(extra):
     assert two.returncode == 0, two.stderr[-2000:]
     a, b = _last_json(one.stdout), _last_json(two.stdout)
     assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["scaling"] == "strong"
+    assert b["config"]["dist"]["world"] == 2 and sum(b["config"]["dist"]["blocks_per_rank"]) == 10 and b["config"]["dist"]["backend"] == "gloo"
     # the cross-rank float64 sum changes the summation order only
     assert np.allclose(a["config"]["sigma_total"], b["config"]["sigma_total"], rtol=1e-9)
     assert np.allclose(a["config"]["sigma_se"], b["config"]["sigma_se"], rtol=1e-7)
@@ -76,3 +77,26 @@ def test_two_ranks_without_a_seed_agree(tmp_path):
     assert a["seed"] == b["seed"] and a["zsum"] == b["zsum"] and a["len_bin"] == b["len_bin"] and sum(a["len_bin"]) == 360
     assert a["sigma"] == b["sigma"] and a["se"] == b["se"]
     assert np.all(np.isfinite(a["sigma"])) and np.all(np.isfinite(a["se"]))
+
+
+def test_rccl_executes_every_collective_of_the_path_on_one_rank():
+    """RCCL itself on the GPU box: the driver's launch line with ONE rank under the "nccl" backend (= RCCL on ROCm) and
+    ``--force-collectives``, so that the in-place float64 all-reduce of every bucket, the (jn - j)-weighted ones of quirk Q4's
+    totals, the packed norm / cross-Gram all-reduce, the tensor all-gather of the leave-one-out systems, barrier(device_ids) and
+    the MAX all-reduce of the timing all go through RCCL (base_streaming.py:21-58's aggregate is what they stand for).  Same
+    sigma^2 and SE as the run without a process group, and the line says what the collectives saw."""
+    args = ["--n-indv", "20000", "--n-snp", "12000", "--jn", "10", "--steps", "1", "--warmup", "1", "--verify", "--no-cpu-baseline",
+            "--no-alt", "--n-bin", "3", "--n-cov", "4", "--compat", "reference"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("PYRHE_DIST_BACKEND", None)
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + args, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    rccl = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                           "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "1", "--force-collectives"] + args,
+                          cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert rccl.returncode == 0, rccl.stderr[-3000:]
+    a, b = _last_json(one.stdout), _last_json(rccl.stdout)
+    assert "dist" not in a["config"]
+    assert b["config"]["dist"] == {"backend": "nccl", "world": 1, "blocks_per_rank": [10], "collectives_forced": True}
+    assert np.allclose(a["config"]["sigma_total"], b["config"]["sigma_total"], rtol=1e-12)
+    assert np.allclose(a["config"]["sigma_se"], b["config"]["sigma_se"], rtol=1e-10)

@@ -712,3 +712,17 @@ def test_cross_columns_dominance_and_api_errors(dev):
     roles = (engine.C.c_int32 * 2)(engine.COL_SKETCH | (2 << 8), engine.COL_NORM)
     assert eng.lib.pyrhe_engine_set_rhs(eng._h, R.data_ptr(), roles, 2, keep.data_ptr(), None) == -1
     eng.close()
+
+
+def test_upload_with_overlapped_recode_equals_upload_then_recode(dev):
+    """models.py loads with ``upload_packed(recode="value")``: every staged piece is recoded on a second stream while the next
+    one crosses PCIe.  Same bytes as the upload followed by pyrhe_recode_rows, over several pieces and a ragged last one."""
+    from pyrhe_amd import engine
+    rng = np.random.default_rng(3)
+    n = 4001
+    rows = rng.integers(0, 256, size=(523, plink.row_bytes(n)), dtype=np.uint8)
+    want = engine.recode_rows(engine.upload_packed(rows, dev), "value")
+    got = engine.upload_packed(rows, dev, chunk_bytes=64 * plink.row_bytes(n), recode="value")       # 9 pieces of 64 rows
+    assert torch.equal(got, want)
+    back = engine.recode_rows(got.clone(), "plink")
+    assert torch.equal(back, engine.upload_packed(rows, dev))

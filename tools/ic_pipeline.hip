@@ -2,14 +2,17 @@
 // served by the 256 MiB Infinity Cache WHILE the first read of the next chunk streams from HBM -- i.e. is the aggregate of the two
 // contractions' read streams above what HBM alone gives (5.9 / 6.4 TB/s for the patterns alone, tools/pattern2.hip)?
 //
-// Pure reads, no arithmetic.  A persistent grid (every workgroup resident) walks PHASES separated by a grid-wide barrier; the
-// genotype rows ([row][pitch], the .bed layout at N = 500k) are cut into chunks of `chunk_rows` rows (32 .. 128 MB).
-//   role A ("GEMM 1"): a workgroup item = 256 rows x 4 steps of 128 B (a wave owns 64 rows, 128 B of every row per step)
-//   role B ("GEMM 2"): a workgroup item = 256 B of every row of the chunk (a wave owns 64 B of every row, 64 rows per step, a
-//                      workgroup barrier every two steps like gemm2_i8p_kernel)
-// modes:  pipe   in phase p half the workgroups stream chunk p (A, from HBM), the other half re-read chunk p - 1 (B)
-//         serial in phase 2c all workgroups run A on chunk c, in phase 2c + 1 all run B on chunk c (the re-read alone)
-//         a-only / b-only  all workgroups run A (B) on chunk p: the patterns alone, cold
+// Pure reads, no arithmetic.  ONE persistent launch (every workgroup resident); the genotype rows ([row][pitch], the .bed layout
+// at N = 500k) are cut into chunks of `chunk_rows` rows (32 .. 192 MB) that both roles walk in order:
+//   role A ("GEMM 1"): item = 256 rows x 4 steps of 128 B (a wave owns 64 rows, 128 B of every row per step), from HBM
+//   role B ("GEMM 2"): item = 256 B of every row of the chunk (a wave owns 64 B of every row, 64 rows per step, a workgroup
+//                      barrier every two steps like gemm2_i8p_kernel) -- the chunk role A has just streamed
+// Chunk-level flags instead of grid barriers (a first version with a grid-wide barrier per chunk measured the barrier, not the
+// memory system: 60 - 150 us per phase of 1024 polling workgroups): a role-A workgroup adds to doneA[c] when its items of chunk c
+// are read, role B starts chunk c when doneA[c] is complete (the dependency of the real pipeline: GEMM 2 needs the chunk's
+// finished X^T R) and adds to doneB[c]; role A starts chunk c only when doneB[c - LAG] is complete, so the two read fronts stay
+// within LAG + 1 chunks of each other -- inside the cache if (LAG + 1) x chunk < 256 MiB.
+// modes: pipe (half / half or other splits), a-only, b-only (all workgroups in one role, no flags: the patterns alone, cold).
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/ic_pipeline tools/ic_pipeline.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -18,15 +21,16 @@
 #include <string.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target) {
+// one lane polls (bounded: about a second -- a protocol error ends with wrong timings, never with a hung GPU), the workgroup follows
+__device__ __forceinline__ void wait_flag(const unsigned* flag, unsigned target) {
+    if (threadIdx.x == 0)
+        for (long it = 0; it < (1l << 20) && __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++it)
+            __builtin_amdgcn_s_sleep(16);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        // bounded poll (about a second): a grid that is not fully resident ends with wrong timings, never with a hung GPU
-        for (long it = 0; it < (1l << 24) && __hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++it)
-            __builtin_amdgcn_s_sleep(2);
-    }
+}
+__device__ __forceinline__ void arrive(unsigned* flag) {
     __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // role A over chunk rows [r0, r0 + nrows): items = (row block of 256, 4-step range); `me` of `nwg` workgroups
@@ -69,36 +73,31 @@ __device__ __forceinline__ uint32_t role_b(const uint8_t* p, int64_t pitch, int 
     return acc;
 }
 
-// mode 0 pipe, 1 serial, 2 a-only, 3 b-only.  split_a: of every 8 consecutive workgroups (one per XCD) groups, how the roles
-// alternate: workgroup w takes role A when ((w / 8) % den) < num  (num / den of the grid streams, the rest re-reads).
-__global__ __launch_bounds__(256) void pipe_kernel(const uint8_t* p, int64_t pitch, int n_chunks, int chunk_rows, int steps_total, int mode,
-                                                   int num, int den, unsigned* counter, uint32_t* sink) {
+// mode 0 pipe, 2 a-only, 3 b-only.  Role split of the pipe: workgroup w (XCD w % 8) takes role A when ((w / 8) % den) < num.
+__global__ __launch_bounds__(256, 8) void pipe_kernel(const uint8_t* p, int64_t pitch, int n_chunks, int chunk_rows, int steps_total, int mode,
+                                                   int num, int den, int lag, unsigned* doneA, unsigned* doneB, uint32_t* sink) {
     const int nwg = gridDim.x, w = blockIdx.x;
     uint32_t acc = 0;
-    unsigned phase = 0;
     if (mode == 0) {
         const int grp = w / 8, xcd = w % 8;
         const bool is_a = (grp % den) < num;
         const int per = nwg / 8 / den;                       // full periods of `den` groups
         const int n_a = per * num * 8, n_b = per * (den - num) * 8;
         const int me = is_a ? ((grp / den) * num + grp % den) * 8 + xcd : ((grp / den) * (den - num) + (grp % den - num)) * 8 + xcd;
-        for (int ph = 0; ph <= n_chunks; ++ph) {
-            if (is_a) { if (ph < n_chunks) acc += role_a(p, pitch, ph * chunk_rows, chunk_rows, steps_total, me, n_a); }
-            else if (ph >= 1) acc += role_b(p, pitch, (ph - 1) * chunk_rows, chunk_rows, me, n_b);
-            grid_barrier(counter, ++phase * nwg);
-        }
-    } else if (mode == 1) {
         for (int c = 0; c < n_chunks; ++c) {
-            acc += role_a(p, pitch, c * chunk_rows, chunk_rows, steps_total, w, nwg);
-            grid_barrier(counter, ++phase * nwg);
-            acc += role_b(p, pitch, c * chunk_rows, chunk_rows, w, nwg);
-            grid_barrier(counter, ++phase * nwg);
+            if (is_a) {
+                if (c >= lag) wait_flag(doneB + (c - lag), (unsigned)n_b);
+                acc += role_a(p, pitch, c * chunk_rows, chunk_rows, steps_total, me, n_a);
+                arrive(doneA + c);
+            } else {
+                wait_flag(doneA + c, (unsigned)n_a);
+                acc += role_b(p, pitch, c * chunk_rows, chunk_rows, me, n_b);
+                arrive(doneB + c);
+            }
         }
     } else {
-        for (int c = 0; c < n_chunks; ++c) {
+        for (int c = 0; c < n_chunks; ++c)
             acc += mode == 2 ? role_a(p, pitch, c * chunk_rows, chunk_rows, steps_total, w, nwg) : role_b(p, pitch, c * chunk_rows, chunk_rows, w, nwg);
-            grid_barrier(counter, ++phase * nwg);
-        }
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
@@ -116,42 +115,42 @@ int main(int argc, char** argv) {
     const int64_t bytes = total_rows * pitch, flush_bytes = (int64_t)8192 * pitch;
     uint8_t* arena; CK(hipMalloc(&arena, bytes + flush_bytes)); CK(hipMemset(arena, 0x5a, bytes + flush_bytes));
     uint32_t* sink; CK(hipMalloc(&sink, 4));
-    unsigned* counter; CK(hipMalloc(&counter, 4));
+    unsigned* flags; CK(hipMalloc(&flags, 2 * 4096 * sizeof(unsigned)));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     int ncu = 0; CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
-    printf("ic_pipeline: %d CUs, pitch %lld B, %lld rows = %.2f GB\n", ncu, (long long)pitch, (long long)total_rows, bytes / 1e9);
-    auto run = [&](const char* name, int mode, int chunk_rows, int wg_per_cu, int num, int den, double reads) -> int {
+    printf("ic_pipeline: %d CUs, pitch %lld B, %lld rows = %.2f GB; rates are bytes READ per second (the pipe reads every byte twice)\n", ncu,
+           (long long)pitch, (long long)total_rows, bytes / 1e9);
+    auto run = [&](const char* name, int mode, int chunk_rows, int wg_per_cu, int num, int den, int lag, double reads) -> int {
         const int n_chunks = (int)(total_rows / chunk_rows);
         const int nwg = ncu * wg_per_cu;
         float best = 1e9f;
         for (int rep = 0; rep < 3; ++rep) {
             linear_kernel<<<4096, 256>>>((const uint4*)(arena + bytes), flush_bytes / 16, sink);
-            CK(hipMemset(counter, 0, 4));
+            CK(hipMemset(flags, 0, 2 * 4096 * sizeof(unsigned)));
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0));
-            pipe_kernel<<<nwg, 256>>>(arena, pitch, n_chunks, chunk_rows, steps_total, mode, num, den, counter, sink);
+            pipe_kernel<<<nwg, 256>>>(arena, pitch, n_chunks, chunk_rows, steps_total, mode, num, den, lag, flags, flags + 4096, sink);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
         }
         const double gb = (double)n_chunks * chunk_rows * pitch * reads / 1e9;
-        printf("%-34s chunk %4d rows = %5.1f MB, %d WG/CU, A:B = %d:%d  %8.1f us  aggregate %5.2f TB/s  (one-read equivalent %5.2f TB/s)\n", name, chunk_rows,
-               chunk_rows * pitch / 1e6, wg_per_cu, num, den - num, best * 1e3, gb / best, gb / reads / best);
+        printf("%-30s chunk %4d rows = %5.1f MB, lag %d, %d WG/CU, A:B = %d:%d  %8.1f us  aggregate %5.2f TB/s  = %5.2f TB/s per read of the genotypes\n", name,
+               chunk_rows, chunk_rows * pitch / 1e6, lag, wg_per_cu, num, den - num, best * 1e3, gb / best, gb / reads / best);
         return 0;
     };
-    for (int wpc : {2, 4}) {
-        if (run("a-only (GEMM 1 pattern, HBM)", 2, 1024, wpc, 1, 2, 1.0)) return 1;
-        if (run("b-only (GEMM 2 pattern, HBM)", 3, 1024, wpc, 1, 2, 1.0)) return 1;
+    for (int wpc : {4, 8}) {
+        if (run("a-only (GEMM 1 pattern, HBM)", 2, 1024, wpc, 1, 2, 0, 1.0)) return 1;
+        if (run("b-only (GEMM 2 pattern, HBM)", 3, 1024, wpc, 1, 2, 0, 1.0)) return 1;
     }
-    for (int rows : {256, 512, 768, 1024, 1536}) {
-        for (int wpc : {2, 4}) {
-            if (run("serial (A then B on the chunk)", 1, rows, wpc, 1, 2, 2.0)) return 1;
-            if (run("pipe   (A on c beside B on c-1)", 0, rows, wpc, 1, 2, 2.0)) return 1;
-        }
-    }
-    // uneven role splits at the two chunk sizes SURVEY 7.3(3) named
+    for (int rows : {256, 512, 768, 1024, 1536})
+        for (int wpc : {4, 8})
+            for (int lag : {1, 2}) {
+                if ((int64_t)(lag + 1) * rows * pitch > (int64_t)420 << 20) continue;        // fronts further apart than the cache could ever hold
+                if (run("pipe (A on c, B on c - lag..c)", 0, rows, wpc, 1, 2, lag, 2.0)) return 1;
+            }
     for (int rows : {512, 1024}) {
-        if (run("pipe, 3 of 4 workgroups stream", 0, rows, 4, 3, 4, 2.0)) return 1;
-        if (run("pipe, 1 of 4 workgroups stream", 0, rows, 4, 1, 4, 2.0)) return 1;
+        if (run("pipe, 3 of 4 workgroups stream", 0, rows, 8, 3, 4, 1, 2.0)) return 1;
+        if (run("pipe, 1 of 4 workgroups stream", 0, rows, 8, 1, 4, 1, 2.0)) return 1;
     }
     return 0;
 }
