@@ -120,7 +120,7 @@ struct pyrhe_engine {
     } sets[2];
     // dominance (RHE_DOM) extras, allocated on first use: one zeroed region (P2 | wmax2) + vsq2, W2, cmu, zeros
     uint8_t* dom_ws = nullptr;
-    size_t dom_zero_bytes = 0;
+    size_t dom_zero_bytes = 0, dom_wmax_off = 0;
     float *P2 = nullptr, *Wtmp2 = nullptr, *cmu = nullptr, *zcoef = nullptr, *vcross2 = nullptr;
     uint32_t* wmax2 = nullptr;
     double* vsq2 = nullptr;
@@ -506,8 +506,9 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
         const size_t oP2 = carve(S * nc * sizeof(float) * (e->i8 ? 3 : 1));
-        const size_t oWm = carve(nc * sizeof(uint32_t));
+        const size_t oWm = carve((size_t)kMaxSeg * kSegCols * sizeof(uint32_t));       // per segment (segmented flow), slot 0 otherwise
         e->dom_zero_bytes = off;
+        e->dom_wmax_off = oWm;
         const size_t oNa = carve(S * PYRHE_MAX_COLS * sizeof(double));
         const size_t oW2 = carve(S * nc * sizeof(float));
         const size_t oCm = carve(S * sizeof(float));
@@ -780,11 +781,16 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     // ---- several bins, additive sketch only: GEMM 1 once per chunk of the concatenated lists, per-bin work by segment
     // (a single list takes this flow too when the packed int8 GEMM 2 applies and the sample range alone fills the chip;
     // small cohorts keep the per-list flow, whose GEMM 2 can split K over workgroups)
-    const bool segflow = !dom && (nbin > 1 || (g2p_ok && e->n_pad >= 192 * 1024));
+    // RHE_DOM takes the segmented flow too (round 3) when both genotype views fit one GEMM 1 launch: one GEMM 1 over the
+    // concatenated lists of several blocks, then THREE GEMM 2 launches over all segments (additive; dominance under the G view;
+    // dominance under the 2 [g == 2] view, accumulating) instead of three per list.
+    const bool dom_seg = dom && e->i8 && e->nt8 <= 4 && e->n_sketch >= 1 && (nbin > 1 || g2p_dom);
+    const bool segflow = dom ? dom_seg : (nbin > 1 || (g2p_ok && e->n_pad >= 192 * 1024));
+    const bool g2p_seg = g2p_ok || (g2p_dom && dom_seg);        // segments padded to the packed GEMM 2's 64-entry K blocks
     e->last_flow = segflow ? 1 : 0;
     // rows beyond the 32-bit offsets of one call: only the packed int8 GEMM 2 addresses a list relative to its lowest row
     // (PYRHE_OPT_LIST_SPAN: the caller vouches for every list spanning < 2^32 bytes and < 2^24 rows)
-    if (wide_rows && !(segflow && g2p_ok))
+    if (wide_rows && !(segflow && g2p_seg))
         return fail(PYRHE_EINVAL, "block of %lld rows x %lld bytes exceeds the 32-bit row offsets of one call on this kernel path; split it",
                     (long long)n_rows, (long long)e->pitch);
     e->last_g2 = 0;
@@ -795,6 +801,9 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 if (out_sketch) HIPCHK(hipMemsetAsync(out_sketch + b * sk_stride, 0, sk_stride * sizeof(float), sB2));
                 if (out_norm && e->n_norm) HIPCHK(hipMemsetAsync(out_norm + (int64_t)b * e->n_norm, 0, e->n_norm * sizeof(double), stream));
                 if (e->n_cross) HIPCHK(hipMemsetAsync(out_cross + b * cr_stride, 0, cr_stride * sizeof(double), stream));
+                if (out_dom) HIPCHK(hipMemsetAsync(out_dom + b * sk_stride, 0, sk_stride * sizeof(float), sB2));
+                if (norm_dom && e->n_norm) HIPCHK(hipMemsetAsync(norm_dom + (int64_t)b * e->n_norm, 0, e->n_norm * sizeof(double), stream));
+                if (cross_dom && e->n_cross) HIPCHK(hipMemsetAsync(cross_dom + b * cr_stride, 0, cr_stride * sizeof(double), stream));
             }
         const int64_t total = offsets_host[nbin];
         const int64_t seg_cap = std::min<int64_t>(e->sub_snps, kG2pSegCap);   // GEMM 2 keeps a segment's row list in LDS
@@ -813,7 +822,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 tab.acc[g] = (accumulate || touched[b]) ? 1 : 0;
                 touched[b] = 1;
                 n += take;
-                kb += g2p_ok ? (g2p_merge ? 4 * ((take + 127) / 128) : 2 * ((take + 63) / 64)) : (take + 31) / 32;   // the packed int8 GEMM 2 walks 64-entry K blocks
+                kb += g2p_seg ? (g2p_merge ? 4 * ((take + 127) / 128) : 2 * ((take + 63) / 64)) : (take + 31) / 32;   // the packed int8 GEMM 2 walks 64-entry K blocks
                 pos += take;
                 // A list cut here (longer than a segment may be, or than the chunk has room for) continues in the NEXT
                 // chunk: its pieces add into the same output slab and norm slot, and only launches are ordered -- the
@@ -828,7 +837,13 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             if (piped && e->sub_counter >= 2) HIPCHK(hipStreamWaitEvent(e->sA, e->evB[set], 0));
             e->sub_counter++;
             { const int rcz = zero_ws(n); if (rcz) return rcz; }
-            run_gemm1(0, rows, n, e->P);
+            if (dom) {      // both genotype views in one launch (one read): P2 and the per-segment maxima of the 2 [g == 2] view
+                HIPCHK(hipMemsetAsync(e->dom_ws, 0, std::min(e->dom_wmax_off, (size_t)n * ncol_p * sizeof(float)), stream));
+                HIPCHK(hipMemsetAsync(e->dom_ws + e->dom_wmax_off, 0, e->dom_zero_bytes - e->dom_wmax_off, stream));
+                run_gemm1(2, rows, n, e->P, e->P2);
+            } else {
+                run_gemm1(0, rows, n, e->P);
+            }
             {
                 ProfScope ps(e, stream, 1);
                 mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
@@ -848,6 +863,26 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                     HIPCHK(hipEventRecord(e->evA[set], e->sA));
                     HIPCHK(hipStreamWaitEvent(sB2, e->evA[set], 0));
                 }
+            }
+            if (dom) {
+                // dominance (rhe_dom.py:15-41; see mid_dom1_kernel): W1 for the G view, W2 for the 2 [g == 2] view, per segment
+                HIPCHK(hipMemsetAsync(e->ws + e->zero_tail, 0, e->zero_bytes - e->zero_tail, stream));      // wmax | corr of every segment
+                {
+                    ProfScope ps(e, stream, 1);
+                    mid_dom1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->P2, pscale, 1, n, ncol_p, e->n_sketch, e->n_norm, e->rscale,
+                                                                         e->csum, (float)e->n_keep, e->cmu, e->Wtmp, e->Wtmp2, e->wmax, e->wmax2,
+                                                                         e->vsq2, e->n_cross, e->vcross2, e->nd2, e->nd3, tab);
+                    if (e->n_cross)
+                        cross_reduce_kernel<<<tab.nseg * (e->n_cross * (e->n_cross + 1) / 2), 256, 0, stream>>>(e->vcross2, e->n_cross, cross_dom, tab);
+                }
+                int rc = run_gemm2(0, e->Wtmp, e->cmu, e->wmax, n, kb, out_dom, false, set, rows, e->n_norm ? e->vsq2 : nullptr,
+                                   e->n_norm ? norm_dom : nullptr, tab, true);
+                if (rc) return rc;
+                HIPCHK(hipMemsetAsync(e->corr, 0, (size_t)kMaxSeg * kSegCols * sizeof(double), stream));
+                SegTab tab2 = tab;
+                for (int g = 0; g < tab2.nseg; ++g) tab2.acc[g] = 1;
+                rc = run_gemm2(1, e->Wtmp2, e->zcoef, e->wmax2, n, kb, out_dom, true, set, rows, nullptr, nullptr, tab2, true);
+                if (rc) return rc;
             }
             if (piped) HIPCHK(hipEventRecord(e->evB[set], sB2));
         }
@@ -926,7 +961,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                     ProfScope ps(e, stream, 1);
                     mid_dom1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->P2, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale,
                                                                          e->csum, (float)e->n_keep, e->cmu, e->Wtmp, e->Wtmp2, e->wmax, e->wmax2,
-                                                                         e->vsq2, e->n_cross, e->vcross2, e->nd2, e->nd3);
+                                                                         e->vsq2, e->n_cross, e->vcross2, e->nd2, e->nd3, tab);
                     if (e->n_norm && !e->n_sketch) norm_reduce_kernel<<<e->n_norm, 256, 0, stream>>>(e->vsq2, e->n_norm, normd, tab);
                     if (e->n_cross) cross_reduce_kernel<<<e->n_cross * (e->n_cross + 1) / 2, 256, 0, stream>>>(e->vcross2, e->n_cross, crossd, tab);
                 }

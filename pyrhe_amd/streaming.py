@@ -429,7 +429,7 @@ class SketchRunner:
         lists of several blocks can go in together: for small cohorts (N = 50k: 62 MB per block) that means one GEMM 1 /
         GEMM 2 launch per ~3 blocks instead of per block.  Bounds: the lists of a batch fit one kernel chunk (entries and
         segment table), the rows of a batch stay within the engine's 32-bit byte offsets."""
-        if self.dom:
+        if self.dom and not self._dom_batches():
             return 1
         cap = int(getattr(self.eng, "sub_snps", 0)) or self.plan.max_block
         by_entries = cap // max(self.plan.max_block, 1)
@@ -442,6 +442,21 @@ class SketchRunner:
         # 1.66 -> 1.77 ms with two more launches: no gain; the largest batch stays.)
         return max(1, min(by_entries, by_bytes, by_lists))
 
+    def _dom_batches(self) -> bool:
+        """RHE_DOM through the engine's segmented flow (several blocks per call, three GEMM 2 launches per call instead of per
+        list): the int8 engine with both genotype views in one GEMM 1 launch (<= 4 tiles) and, for single-bin cohorts, the
+        packed GEMM 2 (<= 10 sketch columns, >= 192k samples) -- the engine's own rule (sketch_impl: dom_seg)."""
+        if not hasattr(self, "n_pass"):
+            return False
+        for e_ in self.engs[:self.n_pass]:
+            if getattr(e_, "precision", "") != "i8x3" or not (1 <= getattr(e_, "n_sketch", 0)):
+                return False
+            slots = int(e_.lib.pyrhe_engine_info(e_._h, 11)) if hasattr(e_, "lib") else 99
+            packed = e_.n_sketch <= 10 and self.n_pad >= 192 * 1024 and getattr(e_, "options", {}).get("g2_packed", 1)
+            if slots > 64 or not (self.plan.n_bin > 1 or packed):
+                return False
+        return True
+
     def _lists_may_span_calls(self) -> bool:
         """Whether one engine call may address more rows than its 32-bit byte offsets reach (N = 500k: more than three
         10 000-SNP blocks): the int8 path with <= 20 sketch columns in the segmented flow addresses every entry list relative
@@ -452,7 +467,8 @@ class SketchRunner:
             if not hasattr(self, "n_pass") or any(getattr(e_, "n_sketch", 0) + getattr(e_, "n_norm", 0) == 0
                                                   for e_ in self.engs[:self.n_pass]):
                 return False               # right-hand sides not installed yet (begin_trait): decide later
-            ok = (not self.dom and self.row_limit is None and all(hasattr(e_, "set_option") for e_ in self.engs[:self.n_pass])
+            ok = (self.row_limit is None and all(hasattr(e_, "set_option") for e_ in self.engs[:self.n_pass])
+                  and (not self.dom or (self._dom_batches() and self.n_pad >= 192 * 1024 and all(e_.n_sketch <= 10 for e_ in self.engs[:self.n_pass])))
                   and all(getattr(e_, "precision", "") == "i8x3" and 1 <= e_.n_sketch <= 20 and
                           getattr(e_, "options", {}).get("g2_packed", 1) for e_ in self.engs[:self.n_pass])
                   and (self.plan.n_bin > 1 or self.n_pad >= 192 * 1024))
@@ -544,10 +560,11 @@ class SketchRunner:
             self._fills[pass_index] = out
         return self._fills[pass_index]
 
-    def sketch_local_blocks(self, out_sk, out_norm, pass_index: int = 0, after_block=None):
+    def sketch_local_blocks(self, out_sk, out_norm, pass_index: int = 0, after_block=None, after_call=None):
         """Enqueue the sketch of every local block: ``out_sk[p][jl]`` / ``out_norm[p][jl]`` receive the per-block
         outputs of engine pass p (``[nbin, n_sketch_p, n_pad]`` float32 / ``[nbin, n_norm_p]`` float64).  With a
-        one-slot store (``recompute_pass2``) every block lands in slot 0 and ``after_block(jl_index, j)`` consumes it."""
+        one-slot store (``recompute_pass2``) every block lands in slot 0 and ``after_block(jl_index, j)`` consumes it;
+        ``after_call(jl0, n)`` runs behind every engine call of the stored form (local blocks jl0 .. jl0 + n - 1 are enqueued)."""
         any_missing = bool(self._check_missing and self._ingest_stats()[1].any())
         block_fills = self._block_fills(pass_index) if any_missing else None
         one_slot = after_block is not None
@@ -589,20 +606,19 @@ class SketchRunner:
                             self._sketch_call(p, rows[a:b], ent_p, offs_p, None if fill is None else fill[a:b].contiguous(),
                                               out_sk[p][jl], out_norm[p][jl], self.blocks_skd[p][jl] if self.dom else None,
                                               self.blocks_nmd[p][jl] if self.dom else None, accumulate=i_ > 0, ocr=ocr, ocrd=ocrd)
-                    elif self.dom:
-                        self._sketch_call(p, rows, ent, offs, fill, out_sk[p][jl], out_norm[p][jl], self.blocks_skd[p][jl],
-                                          self.blocks_nmd[p][jl], ocr=ocr, ocrd=ocrd)
                     else:
                         n = len(js)
-                        osk = out_sk[p][jl:jl + n]
-                        onm = out_norm[p][jl:jl + n]
-                        if has_cr:
-                            ocr = self.blocks_cr[p][jl:jl + n]
-                            ocr = ocr.reshape(n * nb, *ocr.shape[2:])
-                        self._sketch_call(p, rows, ent, offs, fill, osk.reshape(n * nb, *osk.shape[2:]),
-                                          onm.reshape(n * nb, onm.shape[2]), ocr=ocr)
+                        flat = lambda t: t[jl:jl + n].reshape(n * nb, *t.shape[2:])      # [blocks, bins, ...] -> the call's lists
+                        self._sketch_call(p, rows, ent, offs, fill, flat(out_sk[p]), flat(out_norm[p]),
+                                          flat(self.blocks_skd[p]) if self.dom else None, flat(self.blocks_nmd[p]) if self.dom else None,
+                                          ocr=flat(self.blocks_cr[p]) if has_cr else None,
+                                          ocrd=flat(self.blocks_crd[p]) if (has_cr and self.dom) else None)
                 if one_slot:
                     after_block(jl0, js[0])
+                elif after_call is not None:
+                    for eng in pipelined:
+                        eng.join()         # (a no-op unless the engine runs its private two-stream pipeline)
+                    after_call(jl0, len(js))
         finally:
             for eng in pipelined:
                 eng.join()
@@ -790,6 +806,7 @@ class SketchRunner:
         q4 = use_cov and self.streaming and self.compat == "reference"
         w = torch.arange(jn - self.j0, jn - self.j0 - jl, -1, dtype=f64, device=dev) if jl else torch.zeros(0, dtype=f64, device=dev)
         handles = []
+        w_reduced = False             # the (jn - j)-weighted totals of quirk Q4 already went through the collective (per call)
 
         def reduce_async(t):
             if self.collective:
@@ -805,7 +822,59 @@ class SketchRunner:
                     for name in (("Z", "eZ") if self.n_gxe else ("Z",))}
 
         tot_skd = tot_nmd = w_sk = w_skd = tot_crd = None
-        if not self.one_slot:
+        if not self.one_slot and self.collective:
+            # Several ranks: the float64 partial totals of every ENGINE CALL (a batch of blocks) are all-reduced as soon as the
+            # call is enqueued -- RCCL moves them over xGMI on its own stream while the next call's kernels run; only the last
+            # call's exchange is exposed (8 GPUs, 8 bins + covariates: two calls of 8 + 5 blocks per rank, 320 MB each).  The
+            # whole-data totals are the sums of the reduced partials (float64: any order agrees to 1e-16).
+            names = ("Z", "eZ") if self.n_gxe else ("Z",)
+            part = {"sk": [[] for _ in self.blocks_sk], "skd": [[] for _ in self.blocks_sk],
+                    "w": {n_: [[] for _ in self.loc[n_]] for n_ in names}, "wd": {n_: [[] for _ in self.loc[n_]] for n_ in names}}
+
+            rounds = [0]
+
+            def exchange(jl0, n):
+                """One round of collectives: the partial totals of local blocks jl0 .. jl0 + n - 1 (n = 0: zeros -- a rank with
+                fewer engine calls than the largest shard still takes part in every round, in the same order)."""
+                rounds[0] += 1
+                zero = lambda b, nc=None: torch.zeros((b.shape[1], b.shape[2] if nc is None else nc, b.shape[3]), dtype=f64, device=dev)
+                for p_, b in enumerate(self.blocks_sk):
+                    if not b.shape[2]:
+                        continue
+                    part["sk"][p_].append(reduce_async(self.eng.sum_blocks(b[jl0:jl0 + n]) if n else zero(b)))
+                    if self.dom:
+                        bd = self.blocks_skd[p_]
+                        part["skd"][p_].append(reduce_async(self.eng.sum_blocks(bd[jl0:jl0 + n]) if n else zero(bd)))
+                if q4:
+                    for key, store in (("w", self.blocks_sk), ("wd", self.blocks_skd if self.dom else None)):
+                        if store is None:
+                            continue
+                        wt = z_part([(self.eng.sum_blocks(b[jl0:jl0 + n], w[jl0:jl0 + n].contiguous()) if n else zero(b)) if b.shape[2] else None
+                                     for b in store])
+                        for n_, chunks in wt.items():
+                            for i_, t in enumerate(chunks):
+                                part[key][n_][i_].append(reduce_async(t))
+            self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0, after_call=exchange)
+            largest = max(b_ - a_ for a_, b_ in shard_ranges(jn, self.world))
+            for _ in range(rounds[0], -(-largest // max(1, self._blocks_per_call()))):
+                exchange(0, 0)
+            for h in handles:
+                h.wait()
+            handles.clear()
+            total = lambda lst, like: (torch.stack(lst).sum(dim=0) if len(lst) > 1 else lst[0]) if lst else torch.zeros(like.shape[1:], dtype=f64, device=dev)
+            tot_sk = [total(part["sk"][p_], b) for p_, b in enumerate(self.blocks_sk)]
+            tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
+            tot_cr = [b[:jl].sum(dim=0) for b in self.blocks_cr]
+            if self.dom:
+                tot_skd = [total(part["skd"][p_], b) for p_, b in enumerate(self.blocks_skd)]
+                tot_nmd = [b[:jl].sum(dim=0) for b in self.blocks_nmd]
+                tot_crd = [b[:jl].sum(dim=0) for b in self.blocks_crd]
+            if q4:
+                like = lambda n_, i_: self.blocks_sk[self.loc[n_][i_][0]][:, :, :self.loc[n_][i_][3]]
+                w_sk = {n_: [total(lst, like(n_, i_)) for i_, lst in enumerate(part["w"][n_])] for n_ in names}
+                w_skd = {n_: [total(lst, like(n_, i_)) for i_, lst in enumerate(part["wd"][n_])] for n_ in names} if self.dom else None
+            w_reduced = True
+        elif not self.one_slot:
             self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0)
             tot_cr = [b[:jl].sum(dim=0) for b in self.blocks_cr]
             if self.dom:
@@ -853,10 +922,11 @@ class SketchRunner:
             if q4:
                 w_sk, w_skd = z_part(wf), (z_part(wfd) if self.dom else None)
         if self.collective:
-            for d_ in (w_sk, w_skd):
-                for chunks in (d_ or {}).values():
-                    for t in chunks:
-                        reduce_async(t)
+            if not w_reduced:
+                for d_ in (w_sk, w_skd):
+                    for chunks in (d_ or {}).values():
+                        for t in chunks:
+                            reduce_async(t)
             small = tot_nm + (tot_nmd or []) + tot_cr + (tot_crd or [])     # [nbin, n_norm] / [nbin, c, c] each: one packed buffer
             flat = torch.cat([t.reshape(-1) for t in small])
             self._allreduce(flat)

@@ -90,7 +90,7 @@ def test_streaming_q4_weighted_form_close_to_sequential(tmp_path):
 # More ranks than the golden fixtures exercise: uneven shards (jn = 100 over 8 ranks: 13, ..., 13, 9), ranks without a
 # block (world > jn), covariates with the reference-compatible (weighted) UXXz -- all against the one-process run.
 # ----------------------------------------------------------------------------------------------------------------------
-def _synth_runner(n, m, jn, nbin, with_cov, compat):
+def _synth_runner(n, m, jn, nbin, with_cov, compat, blocks_per_call=0):
     from oracle import fixtures
     from oracle import rhe_oracle as O
     from pyrhe_amd.streaming import BlockPlan, SketchRunner, shard_ranges
@@ -109,6 +109,8 @@ def _synth_runner(n, m, jn, nbin, with_cov, compat):
     Z = O.make_probe_vectors(0, n, 4)
     runner = SketchRunner(eng, geno, plan, (j0, j1), n_orig=n, missing_indv=[], Z=Z, cov=c.cov, seed=0, streaming=True,
                           compat=compat)
+    if blocks_per_call:          # several engine calls per rank: one round of collectives per call (SketchRunner.pass1)
+        runner.row_limit = blocks_per_call * plan.max_block
     return runner, y, (j0, j1)
 
 
@@ -128,7 +130,11 @@ def _synth_worker(rank, world, port, shape, out_dir):
                                          (8, (96, 300, 100, 3, 3, "reference")),      # 13 x 7 + 9 blocks, weighted UXXz (Q4)
                                          (8, (96, 300, 100, 1, 3, "fixed")),
                                          (4, (64, 90, 3, 2, 2, "reference")),         # world > jn: one rank has no block
-                                         (8, (64, 100, 10, 1, 0, "reference"))])      # ceil rule: ranks 5..7 empty
+                                         (8, (64, 100, 10, 1, 0, "reference")),       # ceil rule: ranks 5..7 empty
+                                         # four blocks per engine call: 13-block ranks exchange in 4 rounds (4, 4, 4, 1), the 9-block rank's
+                                         # fourth round carries zeros; quirk Q4's weighted totals travel per call too
+                                         (8, (96, 300, 100, 2, 3, "reference", 4)),
+                                         (4, (64, 90, 3, 2, 2, "fixed", 1))])         # a rank without blocks in a 1-round exchange
 def test_many_ranks_uneven_and_empty_shards_equal_one_rank(world, shape, tmp_path):
     from pyrhe_amd.streaming import shard_ranges
     mp.spawn(_synth_worker, args=(world, _free_port(), shape, str(tmp_path)), nprocs=world, join=True)

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 SEED = 20251212          # bench.py's SYNTH_SEED
 
 
-def _setup(n, m, jn, k, nbin=1, n_cov=0, row0=0, materialize=False, genie=None, cross_digits=None):
+def _setup(n, m, jn, k, nbin=1, n_cov=0, row0=0, materialize=False, genie=None, cross_digits=None, dom=False):
     from pyrhe_amd import engine
     from pyrhe_amd.streaming import BlockPlan, SketchRunner, engine_capacity, n_engines_needed
     dev = torch.device("cuda", 0)
@@ -48,6 +48,7 @@ def _setup(n, m, jn, k, nbin=1, n_cov=0, row0=0, materialize=False, genie=None, 
         kw = dict(env=env.reshape(-1, 1), genie_model=genie, compat="fixed")
     p = O.Problem(packed=plink.encode_bed_rows(g), n_indv_orig=n, annot=annot, pheno=y.reshape(-1, 1), n_jack=jn, k=k, seed=0, cov=cov, **kw)
     p.Z = O.make_probe_vectors(0, n, k)
+    p.dom = bool(dom)
     plan = BlockPlan(annot, jn)
     engs = []
     for _ in range(n_engines_needed(k, cov is not None, bool(genie))):
@@ -55,7 +56,7 @@ def _setup(n, m, jn, k, nbin=1, n_cov=0, row0=0, materialize=False, genie=None, 
         e_.set_coding("value")
         engs.append(e_)
     runner = SketchRunner(engs, geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=p.Z, cov=cov, seed=0, streaming=bool(genie),
-                          compat="fixed", materialize_xxuz=materialize, env=env, genie_model=genie, cross_digits=cross_digits)
+                          compat="fixed", materialize_xxuz=materialize, env=env, genie_model=genie, cross_digits=cross_digits, dom=dom)
     return p, runner, engs
 
 
@@ -83,7 +84,7 @@ def _check(p, runner, engs, want_path, blocks_per_call):
     finally:
         O.ACCUM = "reference"
     use_cov = p.cov is not None
-    ne_g = nb * (2 if p.genie_model else 1)                  # G bins, then G x E bins
+    ne_g = nb * (2 if (p.genie_model or p.dom) else 1)       # G bins, then G x E (or dominance) bins
     W = None if not use_cov else np.asarray(p.cov, np.float64)
     # covariates as cross columns (the default): the engine returns S = W^T X X^T W, the runner keeps XXUz as its projection
     # W^T XXUz = S (Q W^T Z) [k, c] -- all the normal equations read of it (base.py:589-591); compared with W^T of the oracle's
@@ -132,7 +133,7 @@ def _check(p, runner, engs, want_path, blocks_per_call):
     sysm = runner.pass2()
     sig = est.solve_all(sysm.T, sysm.q)
     se = np.asarray(est.jackknife_se(sig[:-1], jn))
-    ref = O.genie_results(p, st) if p.genie_model else O.rhe_results(p, st)
+    ref = O.genie_results(p, st) if p.genie_model else (O.rhe_dom_results(p, st) if p.dom else O.rhe_results(p, st))
     assert np.array_equal(sysm.M, st.M)
     # 1e-5 relative per entry; a component below 5 % of the largest one (a bin whose sigma^2 is statistically zero) is
     # judged against 5 % of the largest instead of against itself
@@ -223,6 +224,22 @@ def test_c5_streaming_genie_gxe_at_n500k_vs_oracle():
     p, runner, engs = _setup(500_000, 600, 3, 10, row0=23, genie="G+GxE")
     assert not runner.quirk_last_total and runner.n_est == 2
     _check(p, runner, engs, {"gemm1": 105, "gemm2": 12, "segmented": True, "g2_merged": 1}, blocks_per_call=3)
+
+
+def test_rhe_dom_segmented_flow_at_n200k_vs_oracle():
+    """RHE_DOM through the segmented flow (round 3): three blocks in ONE engine call -- one GEMM 1 launch for both genotype views
+    (gemm1_i8_kernel<3, .., GV = 2>), then three packed GEMM 2 launches over all segments (additive, dominance under the G view,
+    dominance under the 2 [g == 2] view) instead of three per list (rhe_dom.py:15-41, streaming_rhe_dom.py:9-68).  Additive and
+    dominance sketches and norms per block, sigma^2 and SE against the oracle."""
+    p, runner, engs = _setup(200_000, 600, 3, 10, row0=37, dom=True)
+    _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3)
+
+
+def test_rhe_dom_bins_and_covariates_segmented_at_n200k_vs_oracle():
+    """The same with 4 bins and 5 covariates as cross columns under BOTH encodings (S and S_dom per block and bin)."""
+    p, runner, engs = _setup(200_000, 960, 3, 10, nbin=4, n_cov=5, row0=41, dom=True)
+    assert runner.cross and runner.cross_digits == 1         # 10 x 3 + 3 + 5 + 1 = 39 packed digit rows: three tiles
+    _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3)
 
 
 def test_blocks_beyond_one_call_are_split_into_row_pieces():

@@ -2,7 +2,8 @@
 result dicts and log text the REFERENCE produced for the same input files (tests/golden).
 
 Tolerance: 1e-5 relative on every reported number (sigma^2, h2, enrichment and their jackknife SEs), the bound
-BASELINE.json's north_star states, in the parity-safe precision mode f16x2."""
+BASELINE.json's north_star states, in the default (parity-safe) precision mode i8x3 -- both contractions on the int8 matrix
+cores with exact int32 accumulation, covariates as cross columns."""
 import os
 import re
 
