@@ -313,6 +313,9 @@ int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
                                       in such a call only lets lists of one such window share one.  Default 0 (refuse)            */
 #define PYRHE_OPT_G1_FILL 11       /* int8 GEMM 1: among the sample-split counts near the G1_WORKGROUPS target take the one whose
                                       workgroups fill whole rounds of the chip's resident slots best; 0 = the plain target; default 1 */
+#define PYRHE_OPT_DOM_SEG 12       /* pyrhe_engine_sketch_block_dom / _cross with dominance outputs: 1 (default) all lists of a call share
+                                      one GEMM 1 launch (both genotype views) and three GEMM 2 launches (the segmented flow); 0 = one
+                                      kernel sequence per list (round 2's flow)                                                   */
 int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t value);
 
 /* name + average device time (ms, from hipEvents on the launch stream) of the kernels of the last

@@ -152,7 +152,7 @@ struct pyrhe_engine {
     }
     size_t total_bytes = 0;
     // launch-shape knobs (pyrhe_engine_set_option); every value computes the same results
-    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1, opt_list_span = 0, opt_g1_fill = 1, n_cu = 0;
+    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1, opt_list_span = 0, opt_g1_fill = 1, opt_dom_seg = 1, n_cu = 0;
     // kernels of the last sketch call (pyrhe_engine_info 6..8)
     int last_g1 = 0, last_g2 = 0, last_flow = 0, last_g2_merged = 0;
 #ifdef PYRHE_DIAG
@@ -784,7 +784,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
     // RHE_DOM takes the segmented flow too (round 3) when both genotype views fit one GEMM 1 launch: one GEMM 1 over the
     // concatenated lists of several blocks, then THREE GEMM 2 launches over all segments (additive; dominance under the G view;
     // dominance under the 2 [g == 2] view, accumulating) instead of three per list.
-    const bool dom_seg = dom && e->i8 && e->nt8 <= 4 && e->n_sketch >= 1 && (nbin > 1 || g2p_dom);
+    const bool dom_seg = dom && e->opt_dom_seg && e->i8 && e->nt8 <= 4 && e->n_sketch >= 1 && (nbin > 1 || g2p_dom);
     const bool segflow = dom ? dom_seg : (nbin > 1 || (g2p_ok && e->n_pad >= 192 * 1024));
     const bool g2p_seg = g2p_ok || (g2p_dom && dom_seg);        // segments padded to the packed GEMM 2's 64-entry K blocks
     e->last_flow = segflow ? 1 : 0;
@@ -1048,6 +1048,7 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
             e->opt_g1_wide = (int)value; break;
         case PYRHE_OPT_G1_ZERO_ROWS: e->opt_g1_zero_rows = value != 0; break;
         case PYRHE_OPT_G1_FILL: e->opt_g1_fill = value != 0; break;
+        case PYRHE_OPT_DOM_SEG: e->opt_dom_seg = value != 0; break;
         case PYRHE_OPT_LIST_SPAN:
             if (value < 0 || value > (1 << 20)) return fail(PYRHE_EINVAL, "LIST_SPAN %lld outside 0..2^20", (long long)value);
             e->opt_list_span = (int)value; break;

@@ -449,7 +449,7 @@ class SketchRunner:
         if not hasattr(self, "n_pass"):
             return False
         for e_ in self.engs[:self.n_pass]:
-            if getattr(e_, "precision", "") != "i8x3" or not (1 <= getattr(e_, "n_sketch", 0)):
+            if getattr(e_, "precision", "") != "i8x3" or not (1 <= getattr(e_, "n_sketch", 0)) or not getattr(e_, "options", {}).get("dom_seg", 1):
                 return False
             slots = int(e_.lib.pyrhe_engine_info(e_._h, 11)) if hasattr(e_, "lib") else 99
             packed = e_.n_sketch <= 10 and self.n_pad >= 192 * 1024 and getattr(e_, "options", {}).get("g2_packed", 1)

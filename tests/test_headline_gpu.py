@@ -71,8 +71,8 @@ def _check(p, runner, engs, want_path, blocks_per_call):
     sigma^2 and jackknife SE: 1e-5 relative against the reference-order oracle (the north star's bound)."""
     from pyrhe_amd import estimate as est
     jn, N, nb = p.n_jack, p.n_indv, p.nbin
-    assert min(runner._blocks_per_call(), jn) == blocks_per_call         # the blocks of this cohort go in ONE engine call
     runner.begin_trait(p.pheno[:, 0], check_missing=False)
+    assert min(runner._blocks_per_call(), jn) == blocks_per_call         # the blocks of this cohort go in ONE engine call
     runner.pass1()
     torch.cuda.synchronize()
     path = engs[0].last_path()
