@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--materialize-xxuz", action="store_true",
                     help="covariates as the k sketch columns U Z (the reference's XXUz arrays) instead of c cross columns whose "
                          "Gram matrix W^T X X^T W replaces them (SketchRunner.cross)")
+    ap.add_argument("--norm-digits", type=int, default=3, choices=[2, 3],
+                    help="precision experiment: int8 digits of the phenotype column in GEMM 1 (PYRHE_COL_DIGITS; 3 = all 24 bits)")
     ap.add_argument("--compat", default=None, choices=["reference", "fixed"],
                     help="UXXz semantics with covariates (SketchRunner compat); default: fixed with covariates / GENIE")
     ap.add_argument("--force-collectives", action="store_true",
@@ -224,6 +226,7 @@ def main():
     runner = SketchRunner(engines, geno, plan, (j0, j1), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, env=env,
                           genie_model=args.genie, seed=0, streaming=True, dom=args.dom, compat=compat,
                           materialize_xxuz=args.materialize_xxuz, force_collectives=args.force_collectives)
+    runner.norm_digits = args.norm_digits
     runner.begin_trait(y, check_missing=check_missing)      # the generator itself emits no missing calls (contract of synth_kernel)
 
     def barrier():

@@ -285,7 +285,7 @@ class SketchEngine:
         return keep
 
     def set_rhs(self, sketch_cols: Optional[torch.Tensor], norm_cols: Optional[torch.Tensor], keep: torch.Tensor,
-                cross_cols: Optional[torch.Tensor] = None, cross_digits: int = 3):
+                cross_cols: Optional[torch.Tensor] = None, cross_digits: int = 3, norm_digits: int = 3):
         """sketch_cols ``[n_sketch, n_pad]`` / norm_cols ``[n_norm, n_pad]`` / cross_cols ``[n_cross, n_pad]`` float32 on the
         device, zero at dropped and padding samples.  ``cross_digits`` (1..3): int8 digits the cross columns are fed with
         (``PYRHE_COL_DIGITS``)."""
@@ -295,8 +295,9 @@ class SketchEngine:
         ns = 0 if sketch_cols is None else sketch_cols.shape[0]
         nn = 0 if norm_cols is None else norm_cols.shape[0]
         nx = 0 if cross_cols is None else cross_cols.shape[0]
-        assert 1 <= int(cross_digits) <= 3
-        roles = (C.c_int32 * (ns + nn + nx))(*([COL_SKETCH] * ns + [COL_NORM] * nn + [COL_CROSS | (int(cross_digits) << 8)] * nx))
+        assert 1 <= int(cross_digits) <= int(norm_digits) <= 3
+        roles = (C.c_int32 * (ns + nn + nx))(*([COL_SKETCH] * ns + [COL_NORM | (int(norm_digits) << 8)] * nn +
+                                               [COL_CROSS | (int(cross_digits) << 8)] * nx))
         keep = keep.to(torch.float32).contiguous()
         with torch.cuda.device(self.device):
             _check(self.lib.pyrhe_engine_set_rhs(self._h, _ptr(R), roles, ns + nn + nx, _ptr(keep), _stream_ptr(self.device)),

@@ -272,6 +272,7 @@ class SketchRunner:
             self.env_pad = self._pad_cols(torch.from_numpy(self.env[None, :]))[0]            # [n_pad] f64
             self.env32 = self.env_pad.to(torch.float32)
         self.pass2_impl = "hip"       # "torch": materialised cross-check path (tests)
+        self.norm_digits = 3          # int8 digits of the phenotype columns in GEMM 1 (precision experiments: tools/r3_ydigits.sh)
         self.one_slot = False         # this trait group keeps ONE block slot and re-sketches in pass 2 (begin_trait decides)
         self.row_limit = None         # rows one engine call may address; None = from the engine's 32-bit byte offsets
         self._span_ok = None          # see _lists_may_span_calls
@@ -348,9 +349,9 @@ class SketchRunner:
             cr = [cgroups[i] for i, (cp, _) in enumerate(cross_at) if cp == pi]
             if cr:
                 self.engs[pi].set_rhs(sk, nm, self.keep, cross_cols=torch.cat(cr, dim=0).to(torch.float32),
-                                      cross_digits=self.cross_digits)
+                                      cross_digits=self.cross_digits, **({"norm_digits": self.norm_digits} if self.norm_digits != 3 else {}))
             else:
-                self.engs[pi].set_rhs(sk, nm, self.keep)
+                self.engs[pi].set_rhs(sk, nm, self.keep, **({"norm_digits": self.norm_digits} if self.norm_digits != 3 else {}))
             self.pass_shapes.append((col, n_norm_all if pi == 0 else 0))
             self.pass_cross.append(sum(g.shape[0] for g in cr))
         self.loc["y"] = (0, 0)                 # norm columns of pass 0: y of every phenotype, then e.y of every phenotype
