@@ -281,20 +281,24 @@ def main():
     # algorithmic bytes per launch, and only when this run has the shape those passes were taken on; `traffic_source` says
     # which file, which commit and which shape.
     traffic, traffic_source = None, None
-    for tf in ("r02_traffic.json", "r01_traffic.json"):
-        try:
-            with open(os.path.join(REPO, "profiles", tf)) as fh:
-                tj = json.load(fh)
-            key = {"gemm1_kernel": "gemm1_i8_kernel" if g1_i8 else "gemm1_kernel_f16",
-                   "gemm2_kernel": "gemm2_i8p_kernel" if g2_packed else
-                                   ("gemm2_kernel_f16" if args.precision in ("f16", "i8f16") else "gemm2_kernel_f16x2")}[dom]
-            if N == tj["n_indv"] and M // jn == tj["block_snps"] and args.n_bin == 1 and key in tj["kernels"]:
-                traffic = int(tj["kernels"][key]["bytes_per_algorithmic_byte"] * bytes_per_launch)
-                traffic_source = (f"profiles/{tf}@{tj.get('commit', 'r01')}: separate --pmc passes at N={tj['n_indv']}, "
-                                  f"M={tj.get('n_snp', '?')}, jn={tj.get('jn', '?')}, ratio x this run's algorithmic bytes")
-                break
-        except Exception:
-            continue
+    shape = None
+    if not args.dom and not args.materialize_xxuz:
+        if args.n_bin == 1 and not args.n_cov and not args.genie:
+            shape = "1bin"
+        elif args.n_bin == 8 and args.n_cov == 10 and not args.genie:
+            shape = "8bin+10cov"
+        elif args.n_bin == 1 and not args.n_cov and args.genie == "G+GxE":
+            shape = "G+GxE"
+    try:
+        with open(os.path.join(REPO, "profiles", "r03_traffic.json")) as fh:
+            tj = json.load(fh)
+        kern = tj["shapes"][shape]["kernels"][dom_name] if shape else None
+        if kern and N == tj["n_indv"] and M // jn == tj["block_snps"] and k == 10:
+            traffic = int(kern["bytes_per_algorithmic_byte"] * bytes_per_launch)
+            traffic_source = (f"profiles/r03_traffic.json@{tj.get('commit', '?')} [{shape}]: separate --pmc passes at N={tj['n_indv']}, "
+                              f"M={tj.get('n_snp', '?')}, jn={tj.get('jn', '?')}, ratio x this run's algorithmic bytes")
+    except Exception:
+        pass
     # matrix-core work of the dominant kernel as issued (16-column tiles, all limbs / parts), beside the byte roofline:
     # (the fp16 GEMM 2 is bound by instruction issue; the packed int8 GEMM 2 and GEMM 1 by HBM)
     n_pad = engine.n_pad

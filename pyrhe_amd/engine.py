@@ -295,7 +295,8 @@ class SketchEngine:
         ns = 0 if sketch_cols is None else sketch_cols.shape[0]
         nn = 0 if norm_cols is None else norm_cols.shape[0]
         nx = 0 if cross_cols is None else cross_cols.shape[0]
-        assert 1 <= int(cross_digits) <= int(norm_digits) <= 3
+        assert 1 <= int(cross_digits) <= 3 and 1 <= int(norm_digits) <= 3
+        cross_digits = min(int(cross_digits), int(norm_digits))         # digit counts do not grow with the column index
         roles = (C.c_int32 * (ns + nn + nx))(*([COL_SKETCH] * ns + [COL_NORM | (int(norm_digits) << 8)] * nn +
                                                [COL_CROSS | (int(cross_digits) << 8)] * nx))
         keep = keep.to(torch.float32).contiguous()
