@@ -183,9 +183,9 @@ def test_c4_shape_8bins_covariates_at_n200k_vs_oracle():
     """BASELINE config 4's shape (8 bins + 10 covariates incl. the intercept), covariates as CROSS columns (the default): 10
     probes + phenotype + 10 covariates = 21 right-hand columns = 64 packed digit rows = the four-tile int8 GEMM 1; 10 sketch
     columns = the ONE-column-group packed int8 GEMM 2; XXz, yXXy and the projection W^T XXUz = S (Q W^T Z) per block."""
-    p, runner, engs = _setup(200_000, 1200, 3, 10, nbin=8, n_cov=10, row0=5, cross_digits=3)
+    p, runner, engs = _setup(200_000, 720, 3, 10, nbin=8, n_cov=10, row0=5, cross_digits=3)
     assert runner.cross and runner.cross_digits == 3
-    # 24 lists per call (3 blocks x 8 bins of 50 SNPs): three lists share a workgroup of the packed GEMM 2 (PYRHE_OPT_G2_MERGE)
+    # 24 lists per call (3 blocks x 8 bins of 30 SNPs): three lists share a workgroup of the packed GEMM 2 (PYRHE_OPT_G2_MERGE)
     _check(p, runner, engs, {"gemm1": 104, "gemm2": 11, "segmented": True, "g2_merged": 3}, blocks_per_call=3)
 
 
@@ -193,7 +193,7 @@ def test_c4_shape_one_digit_covariates_at_n200k_vs_oracle():
     """The same shape as the product runs it from N = 16 384 on: the covariate columns enter GEMM 1 with ONE int8 digit
     (PYRHE_COL_DIGITS), 10 x 3 + 3 + 10 + 1 = 44 packed digit rows = THREE tiles = the 128-rows-per-wave GEMM 1.  XXz and yXXy per
     block at the usual bounds, W^T XXUz within the 8-bit quantisation of W, sigma^2 and SE within 1e-5 of the oracle."""
-    p, runner, engs = _setup(200_000, 1200, 3, 10, nbin=8, n_cov=10, row0=5)
+    p, runner, engs = _setup(200_000, 720, 3, 10, nbin=8, n_cov=10, row0=5)
     assert runner.cross and runner.cross_digits == 1
     _check(p, runner, engs, {"gemm1": 203, "gemm2": 11, "segmented": True, "g2_merged": 3}, blocks_per_call=3)
 
@@ -201,27 +201,27 @@ def test_c4_shape_one_digit_covariates_at_n200k_vs_oracle():
 def test_c4_shape_materialised_xxuz_at_n200k_vs_oracle():
     """The same shape with the U Z sketch columns materialised (`materialize_xxuz`: the reference's own XXUz arrays, what
     covariate sets too wide for cross columns run): 20 sketch columns = the two-column-group packed int8 GEMM 2."""
-    p, runner, engs = _setup(200_000, 1200, 3, 10, nbin=8, n_cov=10, row0=5, materialize=True)
+    p, runner, engs = _setup(200_000, 720, 3, 10, nbin=8, n_cov=10, row0=5, materialize=True)
     assert not runner.cross
-    # 24 lists per call (3 blocks x 8 bins of 50 SNPs): six lists share a workgroup of the packed GEMM 2 (PYRHE_OPT_G2_MERGE)
+    # 24 lists per call (3 blocks x 8 bins of 30 SNPs): six lists share a workgroup of the packed GEMM 2 (PYRHE_OPT_G2_MERGE)
     _check(p, runner, engs, {"gemm1": 104, "gemm2": 12, "segmented": True, "g2_merged": 6}, blocks_per_call=3)
 
 
 def test_c4_8bins_covariates_at_n500k_vs_oracle():
-    """BASELINE config 4 at ITS cohort size, N = 500 000: 8 bins + 10 covariates, three blocks of 240 SNPs (30 per list) in one
+    """BASELINE config 4 at ITS cohort size, N = 500 000: 8 bins + 10 covariates, three blocks of 160 SNPs (20 per list) in one
     call -- the kernels bench.py --n-bin 8 --n-cov 10 times (three-tile 128-row GEMM 1 with one-digit covariate columns,
     one-group packed GEMM 2 with merged lists)."""
-    p, runner, engs = _setup(500_000, 720, 3, 10, nbin=8, n_cov=10, row0=11)
+    p, runner, engs = _setup(500_000, 480, 3, 10, nbin=8, n_cov=10, row0=11)
     assert runner.cross and runner.cross_digits == 1
     _check(p, runner, engs, {"gemm1": 203, "gemm2": 11, "segmented": True}, blocks_per_call=3)
 
 
 def test_c5_streaming_genie_gxe_at_n500k_vs_oracle():
     """BASELINE config 5 at its cohort size: StreamingGENIE("G+GxE"), N = 500 000, one Bernoulli environment, three blocks of
-    200 SNPs in one call -- Z and e.Z = 20 sketch columns + y, e.y = 22 right-hand columns = 67 digit rows = the FIVE-tile
+    128 SNPs in one call -- Z and e.Z = 20 sketch columns + y, e.y = 22 right-hand columns = 67 digit rows = the FIVE-tile
     int8 GEMM 1 and the two-column-group packed GEMM 2, unmerged (one list per block); per-block X X^T z, e.(X X^T (e.z)),
     both norms, sigma^2 and SE against the oracle's definition of the model (Problem.compat = "fixed", streaming_genie.py:33-49)."""
-    p, runner, engs = _setup(500_000, 600, 3, 10, row0=23, genie="G+GxE")
+    p, runner, engs = _setup(500_000, 384, 3, 10, row0=23, genie="G+GxE")
     assert not runner.quirk_last_total and runner.n_est == 2
     _check(p, runner, engs, {"gemm1": 105, "gemm2": 12, "segmented": True, "g2_merged": 1}, blocks_per_call=3)
 
@@ -231,13 +231,13 @@ def test_rhe_dom_segmented_flow_at_n200k_vs_oracle():
     (gemm1_i8_kernel<3, .., GV = 2>), then three packed GEMM 2 launches over all segments (additive, dominance under the G view,
     dominance under the 2 [g == 2] view) instead of three per list (rhe_dom.py:15-41, streaming_rhe_dom.py:9-68).  Additive and
     dominance sketches and norms per block, sigma^2 and SE against the oracle."""
-    p, runner, engs = _setup(200_000, 600, 3, 10, row0=37, dom=True)
+    p, runner, engs = _setup(200_000, 384, 3, 10, row0=37, dom=True)
     _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3)
 
 
 def test_rhe_dom_bins_and_covariates_segmented_at_n200k_vs_oracle():
     """The same with 4 bins and 5 covariates as cross columns under BOTH encodings (S and S_dom per block and bin)."""
-    p, runner, engs = _setup(200_000, 960, 3, 10, nbin=4, n_cov=5, row0=41, dom=True)
+    p, runner, engs = _setup(200_000, 576, 3, 10, nbin=4, n_cov=5, row0=41, dom=True)
     assert runner.cross and runner.cross_digits == 1         # 10 x 3 + 3 + 5 + 1 = 39 packed digit rows: three tiles
     _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3)
 
