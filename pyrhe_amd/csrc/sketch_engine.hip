@@ -152,7 +152,7 @@ struct pyrhe_engine {
     }
     size_t total_bytes = 0;
     // launch-shape knobs (pyrhe_engine_set_option); every value computes the same results
-    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1, opt_list_span = 0, opt_g1_fill = 1, opt_dom_seg = 1, n_cu = 0;
+    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1, opt_list_span = 0, opt_g1_fill = 1, opt_dom_seg = 1, opt_dots_f32 = 0, n_cu = 0;
     // kernels of the last sketch call (pyrhe_engine_info 6..8)
     int last_g1 = 0, last_g2 = 0, last_flow = 0, last_g2_merged = 0;
 #ifdef PYRHE_DIAG
@@ -554,7 +554,13 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         const int n_steps = n_chunks / g1_ch;             // pitch is a multiple of 256 B = 4 chunks
         const int g1_wgs = std::max(1, e->opt_g1_wgs * 4 / g1_waves);     // target workgroups per launch: 2 rounds of 3 per CU, or (wide: 2 per CU) 3 rounds -- measured 1024 / 1536 / 3072 wide workgroups: 25.3 / 24.5 / 26.5 ms
         int splits = (g1_wgs + gx - 1) / gx;
-        splits = std::max(1, std::min(splits, n_steps / 4 > 0 ? n_steps / 4 : 1));
+        // Every workgroup pays a fixed price -- the prologue and its 128 (64) rows x 16 NT slots of integer atomics per wave --
+        // that a short loop does not amortise: where the row groups alone already fill the chip, no sample range gets fewer than 32
+        // steps (N = 50k, 26 blocks per call: three splits of 32 steps instead of six of 16: GEMM 1 1.44 -> 1.35 ms per pass,
+        // tools/r3_c2_knobs.sh; N = 500k has 70 steps per split either way)
+        int smax = n_steps / 4 > 0 ? n_steps / 4 : 1;
+        if (e->i8 && e->n_cu > 0 && n_steps / 32 >= 1 && (int64_t)gx * (n_steps / 32) >= (int64_t)e->n_cu * 2) smax = std::min(smax, n_steps / 32);
+        splits = std::max(1, std::min(splits, smax));
         int cps = (n_steps + splits - 1) / splits;        // steps per split, even (n_steps is even)
         cps += cps & 1;
         splits = (n_steps + cps - 1) / cps;
@@ -564,7 +570,6 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             // measured at N = 500k with 10 / 20 / 40 blocks per call: 25.5 / 26.0 / 25.9 ms per pass against 23.0 - 23.3 at
             // 13 / 26 blocks (1778 / 2032 workgroups).  Ties go to fewer splits (fewer atomics).
             const int slots = e->n_cu * (wide ? 2 : (e->nt8 <= 3 ? 3 : 2));
-            const int smax = n_steps / 4 > 0 ? n_steps / 4 : 1;
             double best = -1.0;
             for (int s = 1; s <= smax && (int64_t)gx * s <= (int64_t)g1_wgs * 2; ++s) {
                 int c = (n_steps + s - 1) / s;
@@ -1049,6 +1054,7 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
         case PYRHE_OPT_G1_ZERO_ROWS: e->opt_g1_zero_rows = value != 0; break;
         case PYRHE_OPT_G1_FILL: e->opt_g1_fill = value != 0; break;
         case PYRHE_OPT_DOM_SEG: e->opt_dom_seg = value != 0; break;
+        case PYRHE_OPT_DOTS_F32: e->opt_dots_f32 = value != 0; break;
         case PYRHE_OPT_LIST_SPAN:
             if (value < 0 || value > (1 << 20)) return fail(PYRHE_EINVAL, "LIST_SPAN %lld outside 0..2^20", (long long)value);
             e->opt_list_span = (int)value; break;
@@ -1296,7 +1302,8 @@ extern "C" int pyrhe_engine_loo_dots_multi(pyrhe_engine_t* e, const pyrhe_row_t*
         Yf.p[c] = c < ny_flat ? y_flat[c].tot : nullptr;
     }
     dim3 grid((unsigned)((n_chunks + 3) / 4), n_sub, rgs);
-#define LM(F_, S_) blk_multi_dots_kernel<F_, S_><<<grid, 256, 0, stream>>>(tab, nx, nxp, n_batch, Ys, ny_sub, Yf, ny_flat, period, chunk, (int)n_chunks, ps, pf, pg)
+#define LM(F_, S_) do { if (e->opt_dots_f32) blk_multi_dots_kernel<F_, S_, true><<<grid, 256, 0, stream>>>(tab, nx, nxp, n_batch, Ys, ny_sub, Yf, ny_flat, period, chunk, (int)n_chunks, ps, pf, pg); \
+                        else blk_multi_dots_kernel<F_, S_, false><<<grid, 256, 0, stream>>>(tab, nx, nxp, n_batch, Ys, ny_sub, Yf, ny_flat, period, chunk, (int)n_chunks, ps, pf, pg); } while (0)
     if (ny_flat > 0) { if (want_self) LM(true, true); else LM(true, false); }
     else { if (want_self) LM(false, true); else LM(false, false); }
 #undef LM

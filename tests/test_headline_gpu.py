@@ -230,8 +230,8 @@ def test_rhe_dom_segmented_flow_at_n200k_vs_oracle():
 
 
 def test_rhe_dom_bins_and_covariates_segmented_at_n200k_vs_oracle():
-    """The same with 4 bins and 5 covariates as cross columns under BOTH encodings (S and S_dom per block and bin)."""
-    p, runner, engs = _setup(200_000, 576, 3, 10, nbin=4, n_cov=5, row0=41, dom=True)
+    """The same with 2 bins and 5 covariates as cross columns under BOTH encodings (S and S_dom per block and bin)."""
+    p, runner, engs = _setup(200_000, 384, 3, 10, nbin=2, n_cov=5, row0=41, dom=True)
     assert runner.cross and runner.cross_digits == 1         # 10 x 3 + 3 + 5 + 1 = 39 packed digit rows: three tiles
     _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3, with_exact=False)
 
