@@ -1301,9 +1301,10 @@ extern "C" int pyrhe_engine_loo_dots_multi(pyrhe_engine_t* e, const pyrhe_row_t*
         Ys.p[c] = c < ny_sub ? y_sub[c].tot : nullptr;
         Yf.p[c] = c < ny_flat ? y_flat[c].tot : nullptr;
     }
-    dim3 grid((unsigned)((n_chunks + 3) / 4), n_sub, rgs);
-#define LM(F_, S_) do { if (e->opt_dots_f32) blk_multi_dots_kernel<F_, S_, true><<<grid, 256, 0, stream>>>(tab, nx, nxp, n_batch, Ys, ny_sub, Yf, ny_flat, period, chunk, (int)n_chunks, ps, pf, pg); \
-                        else blk_multi_dots_kernel<F_, S_, false><<<grid, 256, 0, stream>>>(tab, nx, nxp, n_batch, Ys, ny_sub, Yf, ny_flat, period, chunk, (int)n_chunks, ps, pf, pg); } while (0)
+    const int64_t ncgs = ((n_chunks + 3) / 4) * (int64_t)n_sub;            // (chunk group, sub-row) pieces of the fixed rows
+    dim3 grid((unsigned)((ncgs + 7) / 8 * 8 * rgs));
+#define LM(F_, S_) do { if (e->opt_dots_f32) blk_multi_dots_kernel<F_, S_, true><<<grid, 256, 0, stream>>>(tab, nx, nxp, n_batch, Ys, ny_sub, Yf, ny_flat, period, chunk, (int)n_chunks, n_sub, rgs, ps, pf, pg); \
+                        else blk_multi_dots_kernel<F_, S_, false><<<grid, 256, 0, stream>>>(tab, nx, nxp, n_batch, Ys, ny_sub, Yf, ny_flat, period, chunk, (int)n_chunks, n_sub, rgs, ps, pf, pg); } while (0)
     if (ny_flat > 0) { if (want_self) LM(true, true); else LM(true, false); }
     else { if (want_self) LM(false, true); else LM(false, false); }
 #undef LM
