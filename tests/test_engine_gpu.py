@@ -434,8 +434,7 @@ def test_loo_dots_multi_equals_separate_calls(dev, nx, nys, nyf, n_sub, batch, w
     y_sub = [Row(ys[b]) for b in range(nys)]
     y_flat = [Row(yf[m]) for m in range(nyf)]
     assert eng.multi_ok(x, y_sub, y_flat, period)
-    if f32:
-        eng.set_option("dots_f32", 1)
+    eng.set_option("dots_f32", 1 if f32 else 0)
     o_sub, o_flat, o_self = eng.loo_dots_multi(x, y_sub, y_flat, want_self, period, n_sub, batch)
     r_sub = eng.loo_dots(x, y_sub, period, n_sub, batch)
     tol = lambda ref: (2e-6 if f32 else 1e-12) * ref.abs().max().item() + 1e-300
