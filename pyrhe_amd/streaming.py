@@ -788,18 +788,67 @@ class SketchRunner:
         C = (e32 * (e32 * self.UZ64.to(f32))).to(f64)[None] if self.cov is not None else None
         return A, C, r
 
+    def _pass1_exchange_rounds(self, q4, w, reduce_async, z_part, handles):
+        """Several ranks: sketch the local blocks and all-reduce the float64 partial totals of every ENGINE CALL (a batch of
+        blocks) as soon as the call is enqueued -- RCCL moves them over xGMI on its own stream while the next call's kernels run;
+        only the last call's exchange is exposed (8 GPUs, 8 bins + covariates: two calls of 8 + 5 blocks per rank, 320 MB each).
+        The whole-data totals are the sums of the reduced partials (float64: any order agrees to 1e-16).  Every rank takes part in
+        ceil(largest shard / blocks per call) rounds, in the same order; a rank with fewer calls (or no block) contributes zeros.
+        Returns (tot_sk, tot_skd, w_sk, w_skd): per-pass totals, their dominance twins, the (jn - j)-weighted XXz of quirk Q4."""
+        jn, dev, f64 = self.plan.n_jack, self.device, torch.float64
+        names = ("Z", "eZ") if self.n_gxe else ("Z",)
+        part = {"sk": [[] for _ in self.blocks_sk], "skd": [[] for _ in self.blocks_sk],
+                "w": {n_: [[] for _ in self.loc[n_]] for n_ in names}, "wd": {n_: [[] for _ in self.loc[n_]] for n_ in names}}
+        rounds = [0]
+        zero = lambda b: torch.zeros(b.shape[1:], dtype=f64, device=dev)
+
+        def exchange(jl0, n):
+            """One round: the partial totals of local blocks jl0 .. jl0 + n - 1 (n = 0: zeros)."""
+            rounds[0] += 1
+            for p_, b in enumerate(self.blocks_sk):
+                if not b.shape[2]:
+                    continue                                   # a pass without sketch columns (cross columns alone)
+                part["sk"][p_].append(reduce_async(self.eng.sum_blocks(b[jl0:jl0 + n]) if n else zero(b)))
+                if self.dom:
+                    bd = self.blocks_skd[p_]
+                    part["skd"][p_].append(reduce_async(self.eng.sum_blocks(bd[jl0:jl0 + n]) if n else zero(bd)))
+            if q4:
+                for key, store in (("w", self.blocks_sk), ("wd", self.blocks_skd if self.dom else None)):
+                    if store is None:
+                        continue
+                    wt = z_part([(self.eng.sum_blocks(b[jl0:jl0 + n], w[jl0:jl0 + n].contiguous()) if n else zero(b)) if b.shape[2] else None
+                                 for b in store])
+                    for n_, chunks in wt.items():
+                        for i_, t in enumerate(chunks):
+                            part[key][n_][i_].append(reduce_async(t))
+        self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0, after_call=exchange)
+        largest = max(b_ - a_ for a_, b_ in shard_ranges(jn, self.world))
+        for _ in range(rounds[0], -(-largest // max(1, self._blocks_per_call()))):
+            exchange(0, 0)
+        for h in handles:
+            h.wait()
+        handles.clear()
+        total = lambda lst, like: (torch.stack(lst).sum(dim=0) if len(lst) > 1 else lst[0]) if lst else zero(like)
+        tot_sk = [total(part["sk"][p_], b) for p_, b in enumerate(self.blocks_sk)]
+        tot_skd = [total(part["skd"][p_], b) for p_, b in enumerate(self.blocks_skd)] if self.dom else None
+        w_sk = w_skd = None
+        if q4:
+            like = lambda n_, i_: self.blocks_sk[self.loc[n_][i_][0]][:, :, :self.loc[n_][i_][3]]
+            w_sk = {n_: [total(lst, like(n_, i_)) for i_, lst in enumerate(part["w"][n_])] for n_ in names}
+            w_skd = {n_: [total(lst, like(n_, i_)) for i_, lst in enumerate(part["wd"][n_])] for n_ in names} if self.dom else None
+        return tot_sk, tot_skd, w_sk, w_skd
+
     def pass1(self):
         """One streaming sketch pass over the local blocks (base_streaming.py:85-104) + aggregate
         (base_streaming.py:21-58 / base.py:465-500: float64 sums in block order) + the cross-GPU all-reduce.
 
-        Multi-GPU (world > 1): the float64 totals are all-reduced IN PLACE, in the engines' own layout
-        ``[bin][sketch column][n_pad]`` (every estimate-level quantity below is linear in them), one asynchronous
-        collective per bucket = (engine pass, array), issued as soon as that bucket's block sum is enqueued so that it
-        overlaps the block sums of the next bucket; the small norm sums travel in one packed buffer.  Float64 on the wire:
-        the single-GPU path adds the blocks in float64 (base.py:468-471 widens every float32 block result before adding),
-        and a float32 hand-over would round every rank's partial sum to 6e-8 -- the 1 / 2 / 4 / 8-GPU results would then
-        agree to 1e-7 instead of 1e-15.  Bytes per rank and pass (ring: x 2 (G-1)/G on the links): k = 10, N = 500k:
-        1 bin 40 MB; 8 bins + covariates 640 MB (+ 320 MB for the (jn - j)-weighted XXz of quirk Q4); G + GxE 80 MB."""
+        Multi-GPU (world > 1): the float64 partial totals of every engine call (a batch of blocks) are all-reduced as soon as
+        the call is enqueued, in the engines' own layout ``[bin][sketch column][n_pad]`` (every estimate-level quantity below is
+        linear in them) -- see _pass1_exchange_rounds; the small norm sums and cross Grams travel in one packed buffer.  Float64
+        on the wire: the single-GPU path adds the blocks in float64 (base.py:468-471 widens every float32 block result before
+        adding), and a float32 hand-over would round every rank's partial sum to 6e-8 -- the 1 / 2 / 4 / 8-GPU results would then
+        agree to 1e-7 instead of 1e-15.  Bytes per rank and pass (ring: x 2 (G-1)/G on the links): k = 10, N = 500k: 1 bin 40 MB;
+        8 bins + covariates (cross columns) 320 MB (+ 320 MB for the (jn - j)-weighted XXz of quirk Q4); G + GxE 80 MB."""
         plan, k = self.plan, self.k
         jn, jl, dev = plan.n_jack, self.j1 - self.j0, self.device
         f64 = torch.float64
@@ -824,56 +873,12 @@ class SketchRunner:
 
         tot_skd = tot_nmd = w_sk = w_skd = tot_crd = None
         if not self.one_slot and self.collective:
-            # Several ranks: the float64 partial totals of every ENGINE CALL (a batch of blocks) are all-reduced as soon as the
-            # call is enqueued -- RCCL moves them over xGMI on its own stream while the next call's kernels run; only the last
-            # call's exchange is exposed (8 GPUs, 8 bins + covariates: two calls of 8 + 5 blocks per rank, 320 MB each).  The
-            # whole-data totals are the sums of the reduced partials (float64: any order agrees to 1e-16).
-            names = ("Z", "eZ") if self.n_gxe else ("Z",)
-            part = {"sk": [[] for _ in self.blocks_sk], "skd": [[] for _ in self.blocks_sk],
-                    "w": {n_: [[] for _ in self.loc[n_]] for n_ in names}, "wd": {n_: [[] for _ in self.loc[n_]] for n_ in names}}
-
-            rounds = [0]
-
-            def exchange(jl0, n):
-                """One round of collectives: the partial totals of local blocks jl0 .. jl0 + n - 1 (n = 0: zeros -- a rank with
-                fewer engine calls than the largest shard still takes part in every round, in the same order)."""
-                rounds[0] += 1
-                zero = lambda b, nc=None: torch.zeros((b.shape[1], b.shape[2] if nc is None else nc, b.shape[3]), dtype=f64, device=dev)
-                for p_, b in enumerate(self.blocks_sk):
-                    if not b.shape[2]:
-                        continue
-                    part["sk"][p_].append(reduce_async(self.eng.sum_blocks(b[jl0:jl0 + n]) if n else zero(b)))
-                    if self.dom:
-                        bd = self.blocks_skd[p_]
-                        part["skd"][p_].append(reduce_async(self.eng.sum_blocks(bd[jl0:jl0 + n]) if n else zero(bd)))
-                if q4:
-                    for key, store in (("w", self.blocks_sk), ("wd", self.blocks_skd if self.dom else None)):
-                        if store is None:
-                            continue
-                        wt = z_part([(self.eng.sum_blocks(b[jl0:jl0 + n], w[jl0:jl0 + n].contiguous()) if n else zero(b)) if b.shape[2] else None
-                                     for b in store])
-                        for n_, chunks in wt.items():
-                            for i_, t in enumerate(chunks):
-                                part[key][n_][i_].append(reduce_async(t))
-            self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0, after_call=exchange)
-            largest = max(b_ - a_ for a_, b_ in shard_ranges(jn, self.world))
-            for _ in range(rounds[0], -(-largest // max(1, self._blocks_per_call()))):
-                exchange(0, 0)
-            for h in handles:
-                h.wait()
-            handles.clear()
-            total = lambda lst, like: (torch.stack(lst).sum(dim=0) if len(lst) > 1 else lst[0]) if lst else torch.zeros(like.shape[1:], dtype=f64, device=dev)
-            tot_sk = [total(part["sk"][p_], b) for p_, b in enumerate(self.blocks_sk)]
+            tot_sk, tot_skd, w_sk, w_skd = self._pass1_exchange_rounds(q4, w, reduce_async, z_part, handles)
             tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
             tot_cr = [b[:jl].sum(dim=0) for b in self.blocks_cr]
             if self.dom:
-                tot_skd = [total(part["skd"][p_], b) for p_, b in enumerate(self.blocks_skd)]
                 tot_nmd = [b[:jl].sum(dim=0) for b in self.blocks_nmd]
                 tot_crd = [b[:jl].sum(dim=0) for b in self.blocks_crd]
-            if q4:
-                like = lambda n_, i_: self.blocks_sk[self.loc[n_][i_][0]][:, :, :self.loc[n_][i_][3]]
-                w_sk = {n_: [total(lst, like(n_, i_)) for i_, lst in enumerate(part["w"][n_])] for n_ in names}
-                w_skd = {n_: [total(lst, like(n_, i_)) for i_, lst in enumerate(part["wd"][n_])] for n_ in names} if self.dom else None
             w_reduced = True
         elif not self.one_slot:
             self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0)
