@@ -91,7 +91,7 @@ def test_linearity_and_block_additivity_at_bench_sample_count():
     eng.close()
 
 
-@pytest.mark.parametrize("case", ["rhe_cov", "genie_nxe_cov", "dom_cov", "rhe_cov_q4", "rhe_recompute"])
+@pytest.mark.parametrize("case", ["rhe_cov", "genie_nxe_cov", "dom_cov", "rhe_cov_q4", "rhe_recompute", "dom_cov_recompute", "genie_materialised"])
 def test_pass2_device_assembly_equals_materialised_torch_path(case):
     """The normal equations assembled from pyrhe_engine_loo_dots (batched, expanded around the whole-data rows,
     covariate projector applied through projections) equal the ones from materialised leave-one-out arrays and torch
@@ -122,6 +122,11 @@ def test_pass2_device_assembly_equals_materialised_torch_path(case):
         kw.update(compat="reference")
     elif case == "rhe_recompute":
         kw.update(recompute_pass2=True)
+    elif case == "dom_cov_recompute":                                # one block slot, re-sketched in pass 2, both encodings' cross Grams
+        kw.update(dom=True, recompute_pass2=True)
+    elif case == "genie_materialised":                               # the U Z / e.U Z sketch columns instead of cross columns
+        kw.update(env=env, genie_model="G+GxE+NxE", materialize_xxuz=True)
+        n_eng = 2
     engs = [engine.SketchEngine(n, n, plan.max_block, device=dev) for _ in range(n_eng)]
     runner = SketchRunner(engs if n_eng > 1 else engs[0], geno, plan, (0, jn), **kw)
     runner.begin_trait(y, check_missing=False)
