@@ -76,7 +76,11 @@ extern "C" {
    beyond, two digits by 5e-8 at N = 500.  Ignored by the fp16 modes. */
 #define PYRHE_COL_DIGITS(d) ((d) << 8)
 
-#define PYRHE_MAX_COLS 30   /* sketch + norm + cross columns (a ones column is appended internally) */
+#define PYRHE_MAX_COLS 46      /* sketch + norm + cross columns of the int8 precisions (a ones column is appended internally), as long as
+                                  their packed digit rows fit six 16-row tiles: columns + 1 + those with >= 2 digits + those with 3 <= 96
+                                  (20 sketch + 2 norm + 20 one-digit cross columns = 87: GENIE G x E with 10 covariates in ONE pass);
+                                  at most 32 of them sketch columns */
+#define PYRHE_MAX_COLS_FP16 30 /* the fp16 precisions: two 16-column operand tiles incl. the ones column */
 
 typedef struct pyrhe_engine pyrhe_engine_t;
 

@@ -161,7 +161,9 @@ struct pyrhe_engine {
 #endif
 };
 
-static constexpr int kMaxTiles = 2;  // 32 logical columns
+static constexpr int kMaxTiles = 2;  // 32 logical columns: fp16 operand tiles, sketch columns of GEMM 2 (all precisions)
+static constexpr int kColCap = 48;   // per-column arrays (scale, sum, maximum): PYRHE_MAX_COLS + the ones column, rounded up
+static_assert(PYRHE_MAX_COLS + 1 <= kColCap, "column arrays hold every user column and the ones column");
 // Packed int8 GEMM 2: dynamic LDS of a workgroup = the row list of its segment group (128 B per 32-entry K block), the
 // per-segment epilogue parameters (correction + 1 / scale of kSegCols columns), the keep mask of its <= 1024 samples and the
 // epilogue's staging buffer (which lies over the row list when the group is one segment); 64 KB at most, so the longest
@@ -231,9 +233,9 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     const int ncolmax = 16 * kMaxTiles;
     e->rfrag_bytes = (size_t)e->n_pad * ncolmax * e->parts * sizeof(_Float16);
     HIPCHK_CREATE(hipMalloc(&e->rfrag, e->rfrag_bytes));
-    HIPCHK_CREATE(hipMalloc(&e->rscale, ncolmax * sizeof(float)));
-    HIPCHK_CREATE(hipMalloc(&e->csum, ncolmax * sizeof(double)));
-    HIPCHK_CREATE(hipMalloc(&e->colmax, ncolmax * sizeof(uint32_t)));
+    HIPCHK_CREATE(hipMalloc(&e->rscale, kColCap * sizeof(float)));
+    HIPCHK_CREATE(hipMalloc(&e->csum, kColCap * sizeof(double)));
+    HIPCHK_CREATE(hipMalloc(&e->colmax, kColCap * sizeof(uint32_t)));
     HIPCHK_CREATE(hipMalloc(&e->keepmask, e->n_pad / 16 * sizeof(uint32_t)));
     HIPCHK_CREATE(hipMalloc(&e->keep, e->n_pad * sizeof(float)));
     // workspace
@@ -327,7 +329,8 @@ extern "C" int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what) {
 extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int32_t* role_host, int n_cols,
                                     const float* keep, void* stream_) {
     if (!e || !R || !role_host || !keep) return fail(PYRHE_EINVAL, "NULL argument");
-    if (n_cols < 1 || n_cols > PYRHE_MAX_COLS) return fail(PYRHE_EINVAL, "n_cols %d outside 1..%d", n_cols, PYRHE_MAX_COLS);
+    const int max_cols = e && e->i8 ? PYRHE_MAX_COLS : PYRHE_MAX_COLS_FP16;
+    if (n_cols < 1 || n_cols > max_cols) return fail(PYRHE_EINVAL, "n_cols %d outside 1..%d", n_cols, max_cols);
     int ns = 0, nn = 0, nx = 0, nd2 = 0, nd3 = 0, last_nd = 3;
     for (int c = 0; c < n_cols; ++c) {
         const int nd = (role_host[c] >> 8) & 3 ? (role_host[c] >> 8) & 3 : 3;
@@ -349,6 +352,13 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
             return fail(PYRHE_EINVAL, "role[%d] = %d is not SKETCH/NORM/CROSS", c, role_host[c]);
         }
     }
+    // fp16 operand image: two 16-column tiles; int8 image: six 16-row tiles of packed (digit, column) rows (the accumulators of
+    // gemm1_i8_kernel<6>, P's 96 slots per entry); the second contraction takes <= 32 sketch columns in every precision.
+    // Checked before anything of the engine's state changes: a refused call leaves the installed columns as they were.
+    const int nslots = n_cols + 1 + nd2 + nd3;
+    if (!e->i8 && (n_cols + 1 + 15) / 16 > kMaxTiles) return fail(PYRHE_EINVAL, "too many columns");
+    if (e->i8 && (nslots + 15) / 16 > 6) return fail(PYRHE_EINVAL, "%d packed digit rows exceed the six tiles of the int8 GEMM 1 (fewer columns or digits)", nslots);
+    if (ns > 16 * kMaxTiles) return fail(PYRHE_EINVAL, "%d sketch columns exceed the %d of the second contraction", ns, 16 * kMaxTiles);
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(e->device));
     if (e->pending) {      // earlier sketches on the internal streams still read the old operand image
@@ -362,13 +372,12 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
     e->ntl = (n_cols + 1 + 15) / 16;
     e->nd2 = nd2;
     e->nd3 = nd3;
-    e->nslots = n_cols + 1 + nd2 + nd3;
-    e->nt8 = (e->nslots + 15) / 16;               // int8 GEMM 1: tiles of packed (digit, column) rows, see i8_slot()
+    e->nslots = nslots;
+    e->nt8 = (nslots + 15) / 16;                  // int8 GEMM 1: tiles of packed (digit, column) rows, see i8_slot()
     e->nto = ns ? (ns + 15) / 16 : 1;
-    if (e->ntl > kMaxTiles) return fail(PYRHE_EINVAL, "too many columns");
     HIPCHK(hipMemcpyAsync(e->keep, keep, e->n_pad * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    HIPCHK(hipMemsetAsync(e->colmax, 0, 16 * kMaxTiles * sizeof(uint32_t), stream));
-    HIPCHK(hipMemsetAsync(e->csum, 0, 16 * kMaxTiles * sizeof(double), stream));
+    HIPCHK(hipMemsetAsync(e->colmax, 0, kColCap * sizeof(uint32_t), stream));
+    HIPCHK(hipMemsetAsync(e->csum, 0, kColCap * sizeof(double), stream));
     {
         dim3 grid((unsigned)std::min<int64_t>((e->n_pad + 255) / 256, 1024), n_cols);
         col_absmax_kernel<<<grid, 256, 0, stream>>>(R, e->n_pad, n_cols, e->colmax);

@@ -100,7 +100,9 @@ class Systems:
     q_all: Optional[np.ndarray] = None   # [n_traits, jn+1, ne+1]: every phenotype sketched in the same pass
 
 
-MAX_ENGINE_COLS = 30            # PYRHE_MAX_COLS of include/pyrhe_sketch.h
+MAX_ENGINE_COLS = 30            # sketch + norm columns of one engine pass (PYRHE_MAX_COLS_FP16 of include/pyrhe_sketch.h)
+MAX_ENGINE_COLS_I8 = 46         # PYRHE_MAX_COLS: an int8 engine takes cross columns beyond the 30, while its packed digit rows
+MAX_DIGIT_ROWS_I8 = 96          # (3 per sketch / norm column, `cross_digits` per cross column, 1 for the ones column) fit six tiles
 MAX_SEGMENTS = 64               # kMaxSeg of the engine: (block, bin) lists one kernel chunk can hold
 
 
@@ -113,27 +115,34 @@ def engine_capacity(plan: "BlockPlan") -> int:
     return max(int(plan.max_block), int(os.environ.get("PYRHE_CAPACITY", "131072")))
 
 
-def plan_passes(k: int, n_groups: int, n_norm: int, cross=()):
+def plan_passes(k: int, n_groups: int, n_norm: int, cross=(), cross_digits: int = 3, wide: bool = False):
     """Distribute ``n_groups`` groups of ``k`` sketch columns (Z, UZ, e.Z, e.UZ) and ``n_norm`` norm columns (all in
     pass 0) over engine passes of at most 30 right-hand columns.  A group stays whole when it fits into the current
     pass or into a fresh one; only groups wider than a pass (num_random_vec > 30 - n_norm) are split.
     Returns, per pass, a list of chunks ``(group index, first column s0, number of columns)``.
     ``cross``: sizes of cross-column groups (the covariates W, e.W: each stays whole, its Gram matrix needs all pairs in one
     pass); then the result is ``(passes, cross_at)`` with ``cross_at[i] = (pass, first cross column of that pass)`` -- the
-    first pass with room, or a pass of its own (one GEMM 1 over the genotypes, no GEMM 2)."""
+    first pass with room, or a pass of its own (one GEMM 1 over the genotypes, no GEMM 2).  ``wide``: int8 engines, which
+    take up to 46 columns as long as the packed digit rows of the pass fit six 16-row tiles (``cross_digits`` rows per cross
+    column: GENIE G x E + 10 one-digit covariates = 20 + 2 + 20 columns = 87 rows in ONE pass)."""
     if cross:
         passes = plan_passes(k, n_groups, n_norm)
-        free = [MAX_ENGINE_COLS - sum(nc for _, _, nc in ch) - (n_norm if pi == 0 else 0) for pi, ch in enumerate(passes)]
+        cap = MAX_ENGINE_COLS_I8 if wide else MAX_ENGINE_COLS
+        cols3 = [sum(nc for _, _, nc in ch) + (n_norm if pi == 0 else 0) for pi, ch in enumerate(passes)]    # three-digit columns
         used, cross_at = [0] * len(passes), []
+
+        def fits(pi, c):
+            rows = 3 * cols3[pi] + cross_digits * (used[pi] + c) + 1
+            return cols3[pi] + used[pi] + c <= cap and (not wide or rows <= MAX_DIGIT_ROWS_I8)
         for c in cross:
-            if c > MAX_ENGINE_COLS:
+            if c > MAX_ENGINE_COLS or (wide and cross_digits * c + 1 > MAX_DIGIT_ROWS_I8):
                 raise ValueError(f"a cross group of {c} columns does not fit one engine pass")
-            pi = next((i for i, f in enumerate(free) if f >= c), None)
+            pi = next((i for i in range(len(passes)) if fits(i, c)), None)
             if pi is None:
-                passes.append([]); free.append(MAX_ENGINE_COLS); used.append(0)
+                passes.append([]); cols3.append(0); used.append(0)
                 pi = len(passes) - 1
             cross_at.append((pi, used[pi]))
-            used[pi] += c; free[pi] -= c
+            used[pi] += c
         return passes, cross_at
     passes, free = [[]], [MAX_ENGINE_COLS - n_norm]
     for g in range(n_groups):
@@ -158,14 +167,14 @@ def n_engines_needed(k: int, use_cov: bool, has_gxe: bool) -> int:
     return len(plan_passes(k, (2 if use_cov else 1) * (2 if has_gxe else 1), 2 if has_gxe else 1))
 
 
-def cross_columns_pay(k: int, c: int, has_gxe: bool) -> bool:
+def cross_columns_pay(k: int, c: int, has_gxe: bool, cross_digits: int = 3, wide: bool = False) -> bool:
     """Whether the covariates go in as CROSS columns (c more columns in GEMM 1, their c x c Gram per (block, bin) out)
     instead of the k sketch columns U Z (k more columns in both contractions, [k, N] rows per (block, bin) out): when that
     takes no more passes over the genotypes than the materialised form."""
     if c < 1 or c > MAX_ENGINE_COLS:
         return False
     g = 2 if has_gxe else 1
-    passes, _ = plan_passes(k, g, g, cross=[c] * g)
+    passes, _ = plan_passes(k, g, g, cross=[c] * g, cross_digits=cross_digits, wide=wide)
     return len(passes) <= n_engines_needed(k, True, has_gxe)
 
 
@@ -255,8 +264,10 @@ class SketchRunner:
         # first contraction as CROSS columns and the engine returns S = W^T X X^T W per (block, bin) -- no U Z sketch
         # columns, half the second contraction, half the stored rows.  ``materialize_xxuz``: the k U Z sketch columns
         # instead (the reference's own arrays; block-wise XXUz tests, or more covariates than a pass has room for).
+        self.cross_digits = int(cross_digits) if cross_digits else (1 if self.N >= 16384 else 3)      # see below
+        self.wide_cols = getattr(self.eng, "precision", "") in ("i8x3", "i8f16")       # int8 engines: up to 46 columns per pass
         self.cross = (self.cov is not None and not materialize_xxuz and
-                      cross_columns_pay(self.k, self.cov.shape[1], self.n_gxe > 0))
+                      cross_columns_pay(self.k, self.cov.shape[1], self.n_gxe > 0, self.cross_digits, self.wide_cols))
         if self.cross:
             self.G64 = torch.from_numpy(self.Q @ (self.cov.T @ self.Z)).to(self.device)      # [c, k]: U Z = W G
             # int8 digits of the covariate columns in the first contraction (PYRHE_COL_DIGITS): S only enters the O(c / N) terms
@@ -266,7 +277,6 @@ class SketchRunner:
             # 128-row GEMM 1) instead of four: 8 bins + 10 covariates at N = 500k 30.5 -> 23.7 ms per pass in GEMM 1.  S itself
             # then carries the 1 % quantisation noise of an 8-bit W (exact for an intercept or 0/1 covariates); small cohorts,
             # where a tile more costs nothing, keep all three digits.  ``cross_digits`` overrides (tests hold S to 2e-5 at 3).
-            self.cross_digits = int(cross_digits) if cross_digits else (1 if self.N >= 16384 else 3)
         self.Z64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.Z.T)))        # [k, n_pad] f64
         if self.env is not None:
             self.env_pad = self._pad_cols(torch.from_numpy(self.env[None, :]))[0]            # [n_pad] f64
@@ -325,7 +335,8 @@ class SketchRunner:
         k = self.k
         n_norm_all = sum(n.shape[0] for n in norms)
         if cgroups:
-            passes, cross_at = plan_passes(k, len(groups), n_norm_all, cross=[g.shape[0] for g in cgroups])
+            passes, cross_at = plan_passes(k, len(groups), n_norm_all, cross=[g.shape[0] for g in cgroups],
+                                           cross_digits=self.cross_digits, wide=self.wide_cols)
         else:
             passes, cross_at = plan_passes(k, len(groups), n_norm_all), []
         if len(passes) > len(self.engs):
@@ -654,7 +665,7 @@ class SketchRunner:
             used = sum(nc for _, _, nc in plan_passes(self.k, per, per)[0])
             best = 1
             for nt in range(1, (MAX_ENGINE_COLS - used) // per + 1):
-                if len(plan_passes(self.k, per, per * nt, cross=[c] * per)[0]) <= len(self.engs):
+                if len(plan_passes(self.k, per, per * nt, cross=[c] * per, cross_digits=self.cross_digits, wide=self.wide_cols)[0]) <= len(self.engs):
                     best = nt
             return best
         n_groups = (2 if self.cov is not None else 1) * (2 if self.n_gxe else 1)

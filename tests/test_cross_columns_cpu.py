@@ -68,3 +68,17 @@ def test_cross_columns_fall_back_when_they_do_not_pay():
     assert len(passes) == 2 and at == [(1, 0), (1, 10)] and passes[1] == []
     passes, at = plan_passes(10, 1, 1, cross=[10])
     assert len(passes) == 1 and at == [(0, 0)]
+
+
+def test_wide_int8_passes_take_cross_columns_beyond_thirty():
+    """An int8 engine takes up to 46 columns while the packed digit rows of the pass fit six tiles (3 per sketch / norm column,
+    `cross_digits` per cross column, 1 for the ones column <= 96): GENIE G x E with 10 one-digit covariates is ONE pass."""
+    from pyrhe_amd.streaming import cross_columns_pay, plan_passes
+    passes, at = plan_passes(10, 2, 2, cross=[10, 10], cross_digits=1, wide=True)          # 20 + 2 + 20 columns, 87 digit rows
+    assert len(passes) == 1 and at == [(0, 0), (0, 10)]
+    passes, at = plan_passes(10, 2, 2, cross=[10, 10], cross_digits=3, wide=True)          # 127 digit rows: a pass of their own (61)
+    assert len(passes) == 2 and at == [(1, 0), (1, 10)]
+    passes, at = plan_passes(10, 2, 2, cross=[15, 15], cross_digits=1, wide=True)          # 52 columns: the second group moves on
+    assert len(passes) == 2 and at == [(0, 0), (1, 0)]
+    assert cross_columns_pay(10, 25, False, cross_digits=1, wide=True) and not cross_columns_pay(10, 25, False)
+    assert not cross_columns_pay(10, 25, False, cross_digits=3, wide=True)                 # 33 + 75 + 1 digit rows

@@ -730,3 +730,48 @@ def test_upload_with_overlapped_recode_equals_upload_then_recode(dev):
     assert torch.equal(got, want)
     back = engine.recode_rows(got.clone(), "plink")
     assert torch.equal(back, engine.upload_packed(rows, dev))
+
+
+def test_wide_int8_pass_42_columns_six_tiles(dev):
+    """PYRHE_MAX_COLS = 46 for the int8 precisions: 20 sketch + 2 norm + 20 one-digit cross columns (GENIE G x E with 10
+    covariates in ONE pass) = 87 packed digit rows = the six-tile GEMM 1; sketches, norms and the cross Gram against float64
+    arithmetic on the decoded genotypes; the fp16 precisions refuse more than 30 columns."""
+    from pyrhe_amd import engine
+    n, m, ks, c = 2003, 300, 20, 20
+    g = synth.synth_rows(20251212, 123, m, n)
+    packed = engine.upload_packed(plink.encode_bed_rows(g), dev)
+    rng = np.random.default_rng(18)
+    Z, y, W = rng.standard_normal((ks, n)), rng.standard_normal((2, n)), rng.standard_normal((c, n))
+    W[:c // 2] = rng.integers(0, 3, (c // 2, n))                      # small-integer covariates: exact in one digit
+    eng = engine.SketchEngine(n, n, max_entries=m, precision="i8x3", device=dev)
+    keep = eng.keep_vector([])
+    pad = lambda a: torch.nn.functional.pad(torch.from_numpy(a.astype(np.float32)), (0, eng.n_pad - n)).to(dev)
+    eng.set_rhs(pad(Z), pad(y), keep, cross_cols=pad(W), cross_digits=1)
+    assert int(eng.lib.pyrhe_engine_info(eng._h, 11)) == 3 * 22 + 20 + 1
+    lists = [np.arange(0, 150, dtype=np.int32), np.arange(150, 300, dtype=np.int32)]
+    ent = torch.from_numpy(np.concatenate(lists)).to(dev)
+    out_cross = torch.zeros((2, c, c), dtype=torch.float64, device=dev)
+    sk, nm, _ = eng.sketch_block(packed, ent, [0, 150, 300], out_cross=out_cross)
+    torch.cuda.synchronize()
+    assert eng.last_path()["gemm1"] == 106
+    for b, rows in enumerate(lists):
+        G = g[rows].astype(np.float32)
+        mu = G.mean(axis=1, dtype=np.float32)
+        d = (np.float32(1) / np.sqrt(mu * (np.float32(1) - np.float32(0.5) * mu))).astype(np.float64)
+        X = (G.astype(np.float64) - mu[:, None].astype(np.float64)) * d[:, None]
+        ref = (X.T @ (X @ Z.astype(np.float32).astype(np.float64).T)).T
+        assert np.abs(sk[b, :, :n].double().cpu().numpy() - ref).max() <= 5e-6 * np.abs(ref).max()
+        for t in range(2):
+            vy = X @ y[t].astype(np.float32).astype(np.float64)
+            assert abs(float(nm[b, t]) - vy @ vy) <= 1e-5 * (vy @ vy)
+        V = X @ W.astype(np.float32).astype(np.float64).T
+        S = V.T @ V
+        got = out_cross[b].cpu().numpy()
+        assert np.abs(got - S).max() <= 2e-2 * np.abs(S).max()
+        h = c // 2
+        assert np.abs(got[:h, :h] - S[:h, :h]).max() <= 5e-6 * np.abs(S[:h, :h]).max()       # the exact (integer) covariates
+    eng.close()
+    e16 = engine.SketchEngine(n, n, max_entries=m, precision="f16x2", device=dev)
+    with pytest.raises(engine.SketchError, match="n_cols"):
+        e16.set_rhs(pad(Z), pad(y), e16.keep_vector([]), cross_cols=pad(W))
+    e16.close()
