@@ -220,6 +220,18 @@ def test_c5_streaming_genie_gxe_at_n500k_vs_oracle():
     _check(p, runner, engs, {"gemm1": 105, "gemm2": 12, "segmented": True, "g2_merged": 1}, blocks_per_call=3, with_exact=False)
 
 
+def test_genie_gxe_covariates_one_wide_pass_vs_oracle():
+    """StreamingGENIE("G+GxE") with 6 covariates at N = 100 000: Z, e.Z (20 sketch columns), y, e.y and the one-digit cross columns
+    W, e.W (12) = 34 right-hand columns in ONE int8 engine pass (PYRHE_MAX_COLS = 46; 79 packed digit rows = the five-tile GEMM 1)
+    where round 2's engine needed two passes; per-block sketches, the projections W^T XXUz of both estimate families, sigma^2 and
+    SE against the oracle (Problem.compat = "fixed")."""
+    p, runner, engs = _setup(100_000, 384, 3, 10, n_cov=6, row0=53, genie="G+GxE")
+    assert runner.cross and runner.cross_digits == 1 and runner.wide_cols
+    runner.begin_trait(p.pheno[:, 0], check_missing=False)
+    assert runner.n_pass == 1 and runner.pass_cross == [12]
+    _check(p, runner, engs, {"gemm1": 105, "gemm2": 12, "segmented": True}, blocks_per_call=3, with_exact=False)
+
+
 def test_rhe_dom_segmented_flow_at_n200k_vs_oracle():
     """RHE_DOM through the segmented flow (round 3): three blocks in ONE engine call -- one GEMM 1 launch for both genotype views
     (gemm1_i8_kernel<3, .., GV = 2>), then three packed GEMM 2 launches over all segments (additive, dominance under the G view,
