@@ -181,11 +181,11 @@ def main():
     keep_idx = np.setdiff1d(np.arange(N), np.asarray(dropped, dtype=np.int64))
     Nk = len(keep_idx)                           # individuals with a phenotype: every per-individual input has this length
     check_missing = args.missing_rate > 0
-    cap = args.sub_snps or engine_capacity(plan)
+    cap = args.sub_snps or engine_capacity(plan, N)
     opts = [(o.split("=", 1)[0], int(o.split("=", 1)[1])) for o in args.opt]
 
     def make_engine(precision, capacity=None):
-        e_ = eng_mod.SketchEngine(N, Nk, max_entries=capacity or engine_capacity(plan), precision=precision, device=dev,
+        e_ = eng_mod.SketchEngine(N, Nk, max_entries=capacity or engine_capacity(plan, N), precision=precision, device=dev,
                                   sub_snps=capacity or cap)
         e_.set_coding(coding)
         for name, val in opts:
@@ -407,7 +407,7 @@ def main():
         sub = BlockPlan(annot[s3:e3], nb3)
         res = {}
         for prec in (args.precision, "f16x2"):
-            engs = [make_engine(prec, engine_capacity(sub)) for _ in range(n_eng)]
+            engs = [make_engine(prec, engine_capacity(sub, N)) for _ in range(n_eng)]
             rn = SketchRunner(engs, geno[s3 - r0:e3 - r0], sub, (0, nb3), n_orig=N, missing_indv=dropped, Z=Z, cov=cov, env=env,
                               genie_model=args.genie, seed=0, streaming=True, compat=compat, solo=True,
                               materialize_xxuz=args.materialize_xxuz)

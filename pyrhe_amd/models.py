@@ -144,8 +144,9 @@ class Base:
         self._runner = None
 
     def _new_engine(self) -> SketchEngine:
-        eng = SketchEngine(self.num_indv_original, self.num_indv, max_entries=engine_capacity(self.plan),
-                           precision=self.precision, device=self.device, sub_snps=self._sub_snps or engine_capacity(self.plan))
+        cap = engine_capacity(self.plan, self.num_indv_original)
+        eng = SketchEngine(self.num_indv_original, self.num_indv, max_entries=cap,
+                           precision=self.precision, device=self.device, sub_snps=self._sub_snps or cap)
         eng.set_coding("value")
         return eng
 

@@ -106,13 +106,16 @@ MAX_DIGIT_ROWS_I8 = 96          # (3 per sketch / norm column, `cross_digits` pe
 MAX_SEGMENTS = 64               # kMaxSeg of the engine: (block, bin) lists one kernel chunk can hold
 
 
-def engine_capacity(plan: "BlockPlan") -> int:
+def engine_capacity(plan: "BlockPlan", n_samples: Optional[int] = None) -> int:
     """``max_entries`` / ``sub_snps`` to create the engines with: at least one block, and room (131 072 entries per kernel
     chunk) to sketch several blocks in one call -- see SketchRunner.sketch_local_blocks.  Measured on MI355X: round 1
     (16 384 -> 65 536) N=50k 71 -> 122 M SNPs/s, N=500k 15.3 -> 16.2 M; round 2, once a call may pass the 32-bit row
     offsets (PYRHE_OPT_LIST_SPAN) and GEMM 1 picks its split count by how the workgroups fill the chip: 65 536 / 131 072 /
-    262 144 entries = 6 / 13 / 26 blocks per call at N=500k: 21.4 / 21.9 / 21.3 M SNPs/s, N=50k 144 / 162 / 165 M."""
-    return max(int(plan.max_block), int(os.environ.get("PYRHE_CAPACITY", "131072")))
+    262 144 entries = 6 / 13 / 26 blocks per call at N=500k: 21.4 / 21.9 / 21.3 M SNPs/s, N=50k 144 / 162 / 165 M.  Round 3
+    (with GEMM 1's 32-steps-per-split rule): N=50k 131 072 / 262 144 / 524 288 entries: 167.7 / 174.8 / 169.2 M SNPs/s; N=100k
+    90.3 / 89.3 M -- so cohorts of up to 65 536 samples (``n_samples``, when the caller gives it) take 262 144."""
+    default = 262144 if (n_samples is not None and n_samples <= 65536) else 131072
+    return max(int(plan.max_block), int(os.environ.get("PYRHE_CAPACITY", str(default))))
 
 
 def plan_passes(k: int, n_groups: int, n_norm: int, cross=(), cross_digits: int = 3, wide: bool = False):

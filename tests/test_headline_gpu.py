@@ -52,7 +52,7 @@ def _setup(n, m, jn, k, nbin=1, n_cov=0, row0=0, materialize=False, genie=None, 
     plan = BlockPlan(annot, jn)
     engs = []
     for _ in range(n_engines_needed(k, cov is not None, bool(genie))):
-        e_ = engine.SketchEngine(n, n, max_entries=engine_capacity(plan), precision="i8x3", device=dev, sub_snps=engine_capacity(plan))
+        e_ = engine.SketchEngine(n, n, max_entries=engine_capacity(plan, n), precision="i8x3", device=dev, sub_snps=engine_capacity(plan, n))
         e_.set_coding("value")
         engs.append(e_)
     runner = SketchRunner(engs, geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=p.Z, cov=cov, seed=0, streaming=bool(genie),
