@@ -217,7 +217,7 @@ def test_c5_streaming_genie_gxe_at_n500k_vs_oracle():
     both norms, sigma^2 and SE against the oracle's definition of the model (Problem.compat = "fixed", streaming_genie.py:33-49)."""
     p, runner, engs = _setup(500_000, 384, 3, 10, row0=23, genie="G+GxE")
     assert not runner.quirk_last_total and runner.n_est == 2
-    _check(p, runner, engs, {"gemm1": 105, "gemm2": 12, "segmented": True, "g2_merged": 1}, blocks_per_call=3, with_exact=False)
+    _check(p, runner, engs, {"gemm1": 105, "gemm2": 12, "segmented": True, "g2_merged": 1}, blocks_per_call=3)
 
 
 def test_genie_gxe_covariates_one_wide_pass_vs_oracle():
@@ -238,7 +238,7 @@ def test_rhe_dom_segmented_flow_at_n200k_vs_oracle():
     dominance under the 2 [g == 2] view) instead of three per list (rhe_dom.py:15-41, streaming_rhe_dom.py:9-68).  Additive and
     dominance sketches and norms per block, sigma^2 and SE against the oracle."""
     p, runner, engs = _setup(200_000, 384, 3, 10, row0=37, dom=True)
-    _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3, with_exact=False)
+    _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3)
 
 
 def test_rhe_dom_bins_and_covariates_segmented_at_n200k_vs_oracle():
