@@ -14,7 +14,11 @@ MI355X-first differences (results identical within the stated tolerance):
     per-bin accumulators are summed with ONE all-reduce (RCCL over xGMI); leave-one-out systems are built
     where the block lives and only ``(ne+1)^2 + ne + 1`` numbers per block are gathered;
   * the Gram matrices of the normal equations and the covariate projector U = W Q W^T come from the engine
-    (``pyrhe_engine_loo_dots*``, ``pyrhe_engine_apply_projector``); torch holds memory and does [blocks, ne, ne] algebra.
+    (``pyrhe_engine_loo_dots*``, ``pyrhe_engine_apply_projector``); torch holds memory and does [blocks, ne, ne] algebra;
+  * with covariates, ``X X^T (U z)`` (base.py:410-412) is kept as its projection ``W^T XXUz = S (Q W^T z)`` only -- all that
+    setup_lhs_rhs_jackknife reads of it (base.py:589-591; UXXz lies in span(W)): the covariates go through the first
+    contraction as CROSS columns and the engine returns ``S = W^T X X^T W`` per (block, bin) instead of k more sketch columns
+    (``SketchRunner.cross``; ``materialize_xxuz=True`` keeps the reference's arrays).
 """
 from __future__ import annotations
 
