@@ -269,3 +269,37 @@ def test_phenotypes_sharing_one_pass_equal_separate_runs(case):
         assert np.allclose(one.q, both.q_all[t], rtol=1e-12, atol=0), t
     for e_ in engs:
         e_.close()
+
+
+def test_seventy_covariates_take_the_fallback_paths_and_match_the_oracle():
+    """More covariates than any fast path holds: 70 columns -- beyond the 30 that cross columns take (so the U Z sketch columns are
+    materialised), beyond the 64 of pyrhe_engine_apply_projector (the torch float32 chain applies U instead: the reference's
+    _compute_UXXz, base.py:407-408) and beyond the 16 flat rows of pyrhe_engine_loo_dots_multi (separate loo_dots calls).  The run
+    must neither refuse nor drift: sigma^2 and SE against the oracle at 1e-5."""
+    from oracle import fixtures
+    from oracle import rhe_oracle as O
+    from pyrhe_amd import engine, estimate as est
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner, n_engines_needed
+    dev = torch.device("cuda", 0)
+    n, m, jn, k, c = 2000, 360, 4, 10, 70
+    coh = fixtures.make_cohort("manycov", n, m, seed=31, nbin=2)
+    rng = np.random.default_rng(4)
+    cov = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, c - 1))], axis=1)
+    y = coh.pheno[:, 0] - coh.pheno[:, 0].mean()
+    p = O.Problem(packed=coh.packed, n_indv_orig=n, annot=coh.annot, pheno=y.reshape(-1, 1), n_jack=jn, k=k, seed=0, cov=cov)
+    p.Z = O.make_probe_vectors(0, n, k)
+    ref = O.rhe_results(p, O.precompute(p))
+    plan = BlockPlan(coh.annot, jn)
+    engs = [engine.SketchEngine(n, n, plan.max_block, device=dev) for _ in range(n_engines_needed(k, True, False))]
+    geno = engine.upload_packed(coh.packed, dev, recode="value")
+    for e_ in engs:
+        e_.set_coding("value")
+    runner = SketchRunner(engs, geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=p.Z, cov=cov, seed=0, streaming=False, compat="fixed")
+    assert not runner.cross and runner.WT32.shape[0] == c
+    sysm = runner.run_trait(y, check_missing=False)
+    sig = est.solve_all(sysm.T, sysm.q)
+    se = np.asarray(est.jackknife_se(sig[:-1], jn))
+    assert np.abs(sig[-1] - ref["sigma_ests_total"]).max() <= 1e-5 * np.abs(ref["sigma_ests_total"]).max()
+    assert np.abs(se - ref["sig_errs"]).max() <= 1e-5 * np.abs(ref["sig_errs"]).max()
+    for e_ in engs:
+        e_.close()
