@@ -75,6 +75,46 @@ class CpuStubEngine:
                 out_norm[b] = torch.from_numpy(nm)
         return out_sketch, out_norm, None
 
+    def sketch_block_dom(self, packed, entries, offsets, *, fill=None, out_sketch=None, out_norm=None, out_sketch_dom=None,
+                         out_norm_dom=None, accumulate=False, out_cross=None, out_cross_dom=None):
+        """Additive + dominance sketches (RHE_DOM, rhe_dom.py:15-41) from oracle math: the additive half as sketch_block, the
+        dominance half with the oracle's encoding and scaling."""
+        self.sketch_block(packed, entries, offsets, fill=fill, out_sketch=out_sketch, out_norm=out_norm, accumulate=accumulate,
+                          out_cross=out_cross)
+        nbin = len(offsets) - 1
+        G = plink.decode_count_a2(packed.numpy(), self.n_pad).T.astype(np.float64)
+        if fill is not None:
+            f = fill.numpy()
+            for r in range(G.shape[0]):
+                G[r, np.isnan(G[r])] = f[r]
+        ent = entries.numpy()
+        for b in range(nbin):
+            rows = ent[offsets[b]:offsets[b + 1]]
+            sk = np.zeros((self.n_sketch, self.n_pad))
+            nm = np.zeros(max(self.n_norm, 1))
+            S = None
+            if len(rows):
+                Gk = np.asfortranarray(G[rows][:, self.keep].astype(np.float32).T)          # [N, m]
+                X = O.standardize_geno_dom(*O.encode_geno_dom(Gk)).astype(np.float64)
+                if self.n_sketch:
+                    sk[:, self.keep] = (X @ (X.T @ self.sk[:, self.keep].T)).T
+                if self.n_norm:
+                    nm[: self.n_norm] = ((X.T @ self.nm[:, self.keep].T) ** 2).sum(axis=0)
+                if self.n_cross:
+                    V = X.T @ self.cr[:, self.keep].T
+                    S = torch.from_numpy(V.T @ V)
+            if self.n_cross:
+                if S is None:
+                    S = torch.zeros((self.n_cross, self.n_cross), dtype=torch.float64)
+                out_cross_dom[b] = out_cross_dom[b] + S if accumulate else S
+            if accumulate:
+                out_sketch_dom[b] += torch.from_numpy(sk).float()
+                out_norm_dom[b] += torch.from_numpy(nm)
+            else:
+                out_sketch_dom[b] = torch.from_numpy(sk).float()
+                out_norm_dom[b] = torch.from_numpy(nm)
+        return out_sketch, out_norm, out_sketch_dom, out_norm_dom
+
     def loo_dots(self, x, y, period, n_sub, n_batch=1):
         """Oracle-side twin of pyrhe_engine_loo_dots (float64 torch on the CPU)."""
         L = period * n_sub

@@ -82,3 +82,29 @@ def test_wide_int8_passes_take_cross_columns_beyond_thirty():
     assert len(passes) == 2 and at == [(0, 0), (1, 0)]
     assert cross_columns_pay(10, 25, False, cross_digits=1, wide=True) and not cross_columns_pay(10, 25, False)
     assert not cross_columns_pay(10, 25, False, cross_digits=3, wide=True)                 # 33 + 75 + 1 digit rows
+
+
+@pytest.mark.parametrize("name,streaming", [("rhe_dom_cov", False), ("srhe_dom_cov", True)])
+def test_rhe_dom_with_cross_columns_matches_the_reference_and_the_materialised_form(name, streaming):
+    """RHE_DOM + covariates on the stand-in engine: S and S_dom (both encodings' cross Grams) in place of the U Z columns --
+    the reference's variance components at 2e-6 and the materialised form's systems at 1e-9."""
+    from pyrhe_amd import estimate as est
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner
+    from tests.cpu_stub_engine import CpuStubEngine
+    z = load_golden(name)
+    p, c = oracle_problem(z)
+    plan = BlockPlan(c.annot, p.n_jack)
+    out = {}
+    for materialize in (False, True):
+        eng = CpuStubEngine(c.n_indv, p.n_indv)
+        geno = torch.zeros((c.packed.shape[0], eng.pitch), dtype=torch.uint8)
+        geno[:, : c.packed.shape[1]] = torch.from_numpy(c.packed.copy())
+        r = SketchRunner(eng, geno, plan, (0, p.n_jack), n_orig=c.n_indv, missing_indv=p.missing_indv, Z=p.Z, cov=p.cov,
+                         impute=p.impute, seed=p.seed, streaming=streaming, compat="reference", dom=True, materialize_xxuz=materialize)
+        assert r.cross == (not materialize)
+        out[materialize] = r.run_trait(p.pheno[:, 0])
+    a, b = out[False], out[True]
+    assert np.abs(a.T - b.T).max() <= 1e-9 * np.abs(b.T).max() and np.allclose(a.q, b.q, rtol=1e-12, atol=0)
+    sig = est.solve_all(a.T, a.q)
+    assert np.allclose(sig[-1], z["ref_t0_res_sigma_ests_total"], rtol=2e-6)
+    assert np.allclose(est.jackknife_se(sig[:-1], p.n_jack), z["ref_t0_res_sig_errs"], rtol=2e-5)

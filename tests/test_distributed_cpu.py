@@ -36,7 +36,7 @@ def _build_runner(name, rank_blocks=None, compat="reference", streaming=True):
     geno = torch.zeros((r1 - r0, eng.pitch), dtype=torch.uint8)
     geno[:, : c.packed.shape[1]] = torch.from_numpy(c.packed[r0:r1].copy())
     runner = SketchRunner(eng, geno, plan, (j0, j1), n_orig=c.n_indv, missing_indv=p.missing_indv, Z=p.Z, cov=p.cov,
-                          impute=p.impute, seed=p.seed, streaming=streaming, compat=compat)
+                          impute=p.impute, seed=p.seed, streaming=streaming, compat=compat, dom=bool(getattr(p, "dom", False)))
     return runner, p, z
 
 
@@ -54,7 +54,8 @@ def _worker(rank, world, port, name, compat, streaming, out_dir):
 
 @pytest.mark.parametrize("name,compat,streaming", [("rhe_3bin_nocov_rem", "reference", True),
                                                   ("rhe_3bin_cov", "fixed", True),
-                                                  ("rhe_1bin_missing", "reference", False)])
+                                                  ("rhe_1bin_missing", "reference", False),
+                                                  ("srhe_dom_cov", "reference", True)])      # RHE_DOM + covariates: both encodings' totals, cross Grams and quirk Q4's weighted sums exchanged
 def test_two_ranks_equal_one_rank_and_reference(name, compat, streaming, tmp_path):
     from pyrhe_amd import estimate as est
     world = 2
