@@ -30,13 +30,17 @@ def _build_runner(name, rank_blocks=None, compat="reference", streaming=True):
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     j0, j1 = shard_ranges(p.n_jack, world)[rank]
-    eng = CpuStubEngine(c.n_indv, p.n_indv)
+    from pyrhe_amd.streaming import n_engines_needed
+    has_gxe = p.genie_model in ("G+GxE", "G+GxE+NxE")
+    eng = [CpuStubEngine(c.n_indv, p.n_indv) for _ in range(n_engines_needed(p.k, p.cov is not None, has_gxe))]
     r0 = plan.range(j0)[0] if j1 > j0 else 0
     r1 = plan.range(j1 - 1)[1] if j1 > j0 else 0
-    geno = torch.zeros((r1 - r0, eng.pitch), dtype=torch.uint8)
+    geno = torch.zeros((r1 - r0, eng[0].pitch), dtype=torch.uint8)
     geno[:, : c.packed.shape[1]] = torch.from_numpy(c.packed[r0:r1].copy())
+    env = None if p.genie_model is None else np.delete(np.asarray(p.env, np.float64).reshape(-1), p.missing_indv)
     runner = SketchRunner(eng, geno, plan, (j0, j1), n_orig=c.n_indv, missing_indv=p.missing_indv, Z=p.Z, cov=p.cov,
-                          impute=p.impute, seed=p.seed, streaming=streaming, compat=compat, dom=bool(getattr(p, "dom", False)))
+                          impute=p.impute, seed=p.seed, streaming=streaming, compat=compat, dom=bool(getattr(p, "dom", False)),
+                          env=env, genie_model=p.genie_model)
     return runner, p, z
 
 
@@ -55,7 +59,8 @@ def _worker(rank, world, port, name, compat, streaming, out_dir):
 @pytest.mark.parametrize("name,compat,streaming", [("rhe_3bin_nocov_rem", "reference", True),
                                                   ("rhe_3bin_cov", "fixed", True),
                                                   ("rhe_1bin_missing", "reference", False),
-                                                  ("srhe_dom_cov", "reference", True)])      # RHE_DOM + covariates: both encodings' totals, cross Grams and quirk Q4's weighted sums exchanged
+                                                  ("srhe_dom_cov", "reference", True),
+                                                  ("genie_gxe_nxe_cov", "reference", False)])   # GENIE G + GxE + NxE + covariates: a second, cross-only engine pass per rank      # RHE_DOM + covariates: both encodings' totals, cross Grams and quirk Q4's weighted sums exchanged
 def test_two_ranks_equal_one_rank_and_reference(name, compat, streaming, tmp_path):
     from pyrhe_amd import estimate as est
     world = 2
