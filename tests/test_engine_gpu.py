@@ -414,8 +414,8 @@ def test_lists_longer_than_a_segment(dev, precision):
 
 @pytest.mark.parametrize("nx,nys,nyf,n_sub,batch,want_self", [(8, 9, 10, 3, 7, True), (3, 5, 0, 2, 9, True), (5, 16, 16, 1, 33, False),
                                                               (16, 1, 4, 2, 4, True), (1, 1, 1, 4, 40, True), (7, 2, 3, 5, 3, False)])
-@pytest.mark.parametrize("f32", [False, True])
-def test_loo_dots_multi_equals_separate_calls(dev, nx, nys, nyf, n_sub, batch, want_self, f32):
+@pytest.mark.parametrize("f32,tiles", [(False, 2), (True, 2), (False, 4), (True, 4)])
+def test_loo_dots_multi_equals_separate_calls(dev, nx, nys, nyf, n_sub, batch, want_self, f32, tiles):
     """pyrhe_engine_loo_dots_multi (one pass over the block rows for the products with the sub-strided fixed rows, with the
     flat fixed rows per sub-row, and with themselves) against the three pyrhe_engine_loo_dots calls it replaces.  ``f32``:
     PYRHE_OPT_DOTS_F32, the products on the float32 matrix instruction with float32 partial sums over 128 elements -- within
@@ -435,6 +435,7 @@ def test_loo_dots_multi_equals_separate_calls(dev, nx, nys, nyf, n_sub, batch, w
     y_flat = [Row(yf[m]) for m in range(nyf)]
     assert eng.multi_ok(x, y_sub, y_flat, period)
     eng.set_option("dots_f32", 1 if f32 else 0)
+    eng.set_option("dots_tiles", tiles)          # 16-row tiles per wave: 2 (default, two waves per SIMD) or 4
     o_sub, o_flat, o_self = eng.loo_dots_multi(x, y_sub, y_flat, want_self, period, n_sub, batch)
     r_sub = eng.loo_dots(x, y_sub, period, n_sub, batch)
     tol = lambda ref: (2e-6 if f32 else 1e-12) * ref.abs().max().item() + 1e-300
