@@ -9,7 +9,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
             k = row["Kernel_Name"].split("(")[0][:48]
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in sorted(agg.items()):
-    if not any(x in k for x in ("gemm1", "gemm2", "mid")):
+    if not any(x in k for x in ("gemm1", "gemm2", "mid", "dots", "sum_blocks")):
         continue
     print(k)
     for c, v in sorted(cs.items()):
