@@ -1064,7 +1064,7 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
         case PYRHE_OPT_G1_FILL: e->opt_g1_fill = value != 0; break;
         case PYRHE_OPT_DOM_SEG: e->opt_dom_seg = value != 0; break;
         case PYRHE_OPT_DOTS_TILES:
-            if (value != 2 && value != 4) return fail(PYRHE_EINVAL, "DOTS_TILES takes 2 or 4");
+            if (value != 1 && value != 2 && value != 4) return fail(PYRHE_EINVAL, "DOTS_TILES takes 1, 2 or 4");
             e->opt_dots_tiles = (int)value; break;
         case PYRHE_OPT_DOTS_F32:
             if (value < 0 || value > 2) return fail(PYRHE_EINVAL, "DOTS_F32 takes 0 (float64), 1 (float32 products) or 2 (automatic)");
@@ -1316,7 +1316,7 @@ extern "C" int pyrhe_engine_loo_dots_multi(pyrhe_engine_t* e, const pyrhe_row_t*
         Yf.p[c] = c < ny_flat ? y_flat[c].tot : nullptr;
     }
     // two tiles (32 block rows) per wave, two waves per SIMD (PYRHE_OPT_DOTS_TILES = 2, the default) or four tiles per wave
-    const int tpw = e->opt_dots_tiles == 4 ? 4 : 2, cpw = tpw == 2 ? 2 : 4;
+    const int tpw = e->opt_dots_tiles, cpw = tpw;      // tiles per wave = chunks per workgroup (1, 2 or 4)
     const int64_t ncgs = ((n_chunks + cpw - 1) / cpw) * (int64_t)n_sub;      // (chunk group, sub-row) pieces of the fixed rows
     dim3 grid((unsigned)((ncgs + 7) / 8 * 8 * rgs));
     // float32 matrix instruction with 128-element float32 partial sums (PYRHE_OPT_DOTS_F32): automatic from 65 536 samples on,
@@ -1324,8 +1324,8 @@ extern "C" int pyrhe_engine_loo_dots_multi(pyrhe_engine_t* e, const pyrhe_row_t*
     // sigma^2 unchanged to 16 digits, jackknife SEs 5e-9; tools/r3_dots_f32.sh); small cohorts, which gain nothing, stay float64
     const bool dots_f32 = e->opt_dots_f32 == 1 || (e->opt_dots_f32 == 2 && period >= 65536);
 #define LMK(F_, S_, X_, T_) blk_multi_dots_kernel<F_, S_, X_, T_><<<grid, 256, 0, stream>>>(tab, nx, nxp, n_batch, Ys, ny_sub, Yf, ny_flat, period, chunk, (int)n_chunks, n_sub, rgs, ps, pf, pg)
-#define LM(F_, S_) do { if (dots_f32) { if (tpw == 2) LMK(F_, S_, true, 2); else LMK(F_, S_, true, 4); } \
-                        else { if (tpw == 2) LMK(F_, S_, false, 2); else LMK(F_, S_, false, 4); } } while (0)
+#define LM(F_, S_) do { if (dots_f32) { if (tpw == 1) LMK(F_, S_, true, 1); else if (tpw == 2) LMK(F_, S_, true, 2); else LMK(F_, S_, true, 4); } \
+                        else { if (tpw == 1) LMK(F_, S_, false, 1); else if (tpw == 2) LMK(F_, S_, false, 2); else LMK(F_, S_, false, 4); } } while (0)
     if (ny_flat > 0) { if (want_self) LM(true, true); else LM(true, false); }
     else { if (want_self) LM(false, true); else LM(false, false); }
 #undef LM

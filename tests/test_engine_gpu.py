@@ -414,7 +414,7 @@ def test_lists_longer_than_a_segment(dev, precision):
 
 @pytest.mark.parametrize("nx,nys,nyf,n_sub,batch,want_self", [(8, 9, 10, 3, 7, True), (3, 5, 0, 2, 9, True), (5, 16, 16, 1, 33, False),
                                                               (16, 1, 4, 2, 4, True), (1, 1, 1, 4, 40, True), (7, 2, 3, 5, 3, False)])
-@pytest.mark.parametrize("f32,tiles", [(False, 2), (True, 2), (False, 4), (True, 4)])
+@pytest.mark.parametrize("f32,tiles", [(False, 2), (True, 2), (False, 4), (True, 4), (True, 1)])
 def test_loo_dots_multi_equals_separate_calls(dev, nx, nys, nyf, n_sub, batch, want_self, f32, tiles):
     """pyrhe_engine_loo_dots_multi (one pass over the block rows for the products with the sub-strided fixed rows, with the
     flat fixed rows per sub-row, and with themselves) against the three pyrhe_engine_loo_dots calls it replaces.  ``f32``:
