@@ -301,8 +301,9 @@ int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
 #define PYRHE_OPT_G2_IW 3         /* fp16 GEMM 2: dwords per lane per row (1 / 2); 0 = automatic                    */
 #define PYRHE_OPT_G2_SPLITS 4     /* fp16 GEMM 2, per-list flow: K splits over workgroups; 0 = automatic           */
 #define PYRHE_OPT_DOTS_GENERIC 5  /* 1: pyrhe_engine_loo_dots always takes the register-tiled generic kernel        */
-#define PYRHE_OPT_G1_SPLIT_MAJOR 6 /* 1: GEMM 1 grid with the sample split as the fast index (co-resident workgroups
-                                      share rows); default 0                                                        */
+#define PYRHE_OPT_G1_SPLIT_MAJOR 6 /* GEMM 1 grid order.  0: row group fast; 1: sample split fast (co-resident workgroups
+                                      share rows); 2 (int8 kernels): every XCD works through its own run of sample ranges, whose
+                                      slice of the operand image then stays in that XCD's L2                         */
 #define PYRHE_OPT_G1_WIDE 7        /* int8 GEMM 1 with 128 rows per wave (gemm1_i8w_kernel: half the R-image traffic): 0 never,
                                       1 (default) up to three tiles and >= 196 608 samples or enough rows per call to fill the chip, 2 whenever the registers allow (<= 4)  */
 #define PYRHE_OPT_G2_MERGE 8       /* packed int8 GEMM 2: consecutive short segments (bins of a block) share a workgroup while the
@@ -327,6 +328,8 @@ int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
 #define PYRHE_OPT_DOTS_TILES 14    /* pyrhe_engine_loo_dots_multi: 16-row tiles of block rows per wave: 4 (a wave owns the 64 rows of its
                                       row group; one wave per SIMD), 2 (default: wave pairs share a chunk, two waves per SIMD) or 1
                                       (four waves per SIMD).  Pass 2 at 8 bins + covariates, N = 500k: 9.3 / 8.2 / 12.7 ms        */
+#define PYRHE_OPT_G1_LINE 15       /* int8 GEMM 1 with more than three tiles (256-sample steps): 1 (default) a register stage holds both
+                                      halves of a 128-byte line, loaded together; 0 = 64 bytes per row and step                  */
 int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t value);
 
 /* name + average device time (ms, from hipEvents on the launch stream) of the kernels of the last

@@ -152,7 +152,7 @@ struct pyrhe_engine {
     }
     size_t total_bytes = 0;
     // launch-shape knobs (pyrhe_engine_set_option); every value computes the same results
-    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1, opt_list_span = 0, opt_g1_fill = 1, opt_dom_seg = 1, opt_dots_f32 = 2, opt_dots_tiles = 2, n_cu = 0;
+    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1, opt_list_span = 0, opt_g1_fill = 1, opt_dom_seg = 1, opt_dots_f32 = 2, opt_dots_tiles = 2, opt_g1_line = 1, n_cu = 0;
     // kernels of the last sketch call (pyrhe_engine_info 6..8)
     int last_g1 = 0, last_g2 = 0, last_flow = 0, last_g2_merged = 0;
 #ifdef PYRHE_DIAG
@@ -570,8 +570,11 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         int smax = n_steps / 4 > 0 ? n_steps / 4 : 1;
         if (e->i8 && e->n_cu > 0 && n_steps / 32 >= 1 && (int64_t)gx * (n_steps / 32) >= (int64_t)e->n_cu * 2) smax = std::min(smax, n_steps / 32);
         splits = std::max(1, std::min(splits, smax));
-        int cps = (n_steps + splits - 1) / splits;        // steps per split, even (n_steps is even)
-        cps += cps & 1;
+        // full-line loads of the 256-sample-step kernels (gemm1_i8_kernel<.., LINE>): splits of whole line PAIRS (4 chunks)
+        const bool line = e->i8 && !wide && g1_ch == 1 && e->opt_g1_line && gv != 2;      // both views at once: no registers left
+        const int cmul = line ? 4 : 2;
+        auto round_cps = [&](int c) { return (c + cmul - 1) / cmul * cmul; };
+        int cps = round_cps((n_steps + splits - 1) / splits);        // steps per split, even (n_steps is even; a multiple of 4 chunks)
         splits = (n_steps + cps - 1) / cps;
         if (e->i8 && e->opt_g1_fill && e->n_cu > 0) {
             // Among the split counts that give 0.65 .. 1.7 x the target, take the one whose workgroups fill whole rounds of the
@@ -581,8 +584,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             const int slots = e->n_cu * (wide ? 2 : (e->nt8 <= 3 ? 3 : 2));
             double best = -1.0;
             for (int s = 1; s <= smax && (int64_t)gx * s <= (int64_t)g1_wgs * 2; ++s) {
-                int c = (n_steps + s - 1) / s;
-                c += c & 1;
+                const int c = round_cps((n_steps + s - 1) / s);
                 const int s2 = (n_steps + c - 1) / c;
                 const int64_t wgs = (int64_t)gx * s2;
                 if (wgs * 100 < (int64_t)g1_wgs * 65 || wgs * 10 > (int64_t)g1_wgs * 17) continue;
@@ -593,8 +595,12 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         float* saveP = e->P;
         e->P = Pbuf;
         ProfScope ps(e, stream, 0);
-        const int sm = e->opt_g1_split_major ? 1 : 0;      // grid order: which of (row group, sample split) is the fast index
-        dim3 grid(sm ? splits : gx, sm ? gx : splits);
+        // grid order (g1_grid_index): 0 row group fast, 1 sample split fast, 2 every XCD works through its own run of sample ranges
+        // (int8 kernels only; the mode word then carries the row-group count)
+        const int smode = e->i8 ? e->opt_g1_split_major : (e->opt_g1_split_major == 1);
+        const int sm = smode == 2 ? (2 | (gx << 2)) : smode;
+        dim3 grid(smode == 1 ? splits : gx, smode == 1 ? gx : splits);
+        if (smode == 2) grid = dim3((unsigned)(((int64_t)gx * splits + 7) / 8 * 8), 1);
         int ua = splits > 1, g1_diag = 0;
 #ifdef PYRHE_DIAG
         if (ua && e->diag_g1_plain_store) ua = 2;          // WRONG results: plain stores instead of atomics, to price the atomics
@@ -605,8 +611,11 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         const int live_last = e->opt_g1_zero_rows ? e->nslots - 16 * (e->nt8 - 1) : 16;     // live digit rows of the last int8 tile
         if (e->i8) {
             const size_t lds = (size_t)2 * g1_ch * 4 * e->nt8 * 1024;
-#define G1I(NT_, MISS_, GV_) do { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag, live_last); \
-                                  else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag, live_last); } while (0)
+#define G1A (packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag, live_last)
+#define G1I(NT_, MISS_, GV_) do { if (NT_ > 3 && line) { if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true, 4, (NT_ > 3 && GV_ != 2)><<<grid, 256, lds, stream>>>G1A; \
+                                                        else gemm1_i8_kernel<NT_, MISS_, GV_, false, 4, (NT_ > 3 && GV_ != 2)><<<grid, 256, lds, stream>>>G1A; } \
+                                  else if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>G1A; \
+                                  else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>G1A; } while (0)
 #define G1X(NT_, MISS_) do { if (e->vc) gemm1_i8w_kernel<NT_, MISS_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, sm, live_last); \
                              else gemm1_i8w_kernel<NT_, MISS_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, sm, live_last); } while (0)
 #define G1J(NT_) do { if (wide) { if (fill) G1X(NT_, true); else G1X(NT_, false); break; } if (gv == 0) { if (fill) G1I(NT_, true, 0); else G1I(NT_, false, 0); } \
@@ -623,6 +632,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
 #undef G1J
 #undef G1X
 #undef G1I
+#undef G1A
         } else {
 #define G1(NTL_, PARTS_, EX_, GV_) launch_gemm1<NTL_, PARTS_, EX_, GV_>(e, packed, rows, n, fill, n_steps, cps, splits, stream)
             if (gv == 0) {
@@ -1056,12 +1066,15 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
             if (value < 0 || value > 4096) return fail(PYRHE_EINVAL, "G2_SPLITS %lld outside 0..4096", (long long)value);
             e->opt_g2_splits = (int)value; break;
         case PYRHE_OPT_DOTS_GENERIC: e->opt_dots_generic = value != 0; break;
-        case PYRHE_OPT_G1_SPLIT_MAJOR: e->opt_g1_split_major = value != 0; break;
+        case PYRHE_OPT_G1_SPLIT_MAJOR:
+            if (value < 0 || value > 2) return fail(PYRHE_EINVAL, "G1_SPLIT_MAJOR takes 0 (row group fast), 1 (sample split fast) or 2 (sample ranges per XCD)");
+            e->opt_g1_split_major = (int)value; break;
         case PYRHE_OPT_G1_WIDE:
             if (value < 0 || value > 2) return fail(PYRHE_EINVAL, "G1_WIDE takes 0 (never), 1 (automatic) or 2 (whenever possible)");
             e->opt_g1_wide = (int)value; break;
         case PYRHE_OPT_G1_ZERO_ROWS: e->opt_g1_zero_rows = value != 0; break;
         case PYRHE_OPT_G1_FILL: e->opt_g1_fill = value != 0; break;
+        case PYRHE_OPT_G1_LINE: e->opt_g1_line = value != 0; break;
         case PYRHE_OPT_DOM_SEG: e->opt_dom_seg = value != 0; break;
         case PYRHE_OPT_DOTS_TILES:
             if (value != 1 && value != 2 && value != 4) return fail(PYRHE_EINVAL, "DOTS_TILES takes 1, 2 or 4");

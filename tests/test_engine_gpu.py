@@ -593,7 +593,8 @@ def test_gemm1_launch_shape_options_do_not_change_a_bit(dev):
     entries = torch.from_numpy(np.concatenate(lists)).to(dev)
     res, paths = [], set()
     for opts in ({}, {"g1_fill": 0}, {"g1_workgroups": 300}, {"g1_workgroups": 5000}, {"g1_wide": 0}, {"g1_wide": 2},
-                 {"g1_wide": 2, "g1_workgroups": 700, "g1_split_major": 1}, {"g1_zero_rows": 0}):
+                 {"g1_wide": 2, "g1_workgroups": 700, "g1_split_major": 1}, {"g1_zero_rows": 0},
+                 {"g1_split_major": 2}, {"g1_wide": 0, "g1_split_major": 2, "g1_workgroups": 1000}):
         eng = engine.SketchEngine(n, n, max_entries=m, precision="i8x3", device=dev, sub_snps=32768)
         eng.set_coding("value")
         for name, v in opts.items():
@@ -611,6 +612,50 @@ def test_gemm1_launch_shape_options_do_not_change_a_bit(dev):
         res.append([t.clone() for t in (sk, nm, cs)])
         eng.close()
     assert paths == {103, 203}                                  # both int8 GEMM 1 kernels took part
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("k,n_norm,tiles", [(16, 1, 4), (20, 2, 5), (26, 2, 6)])
+@pytest.mark.parametrize("with_fill,coding", [(False, "value"), (True, "value"), (True, "plink")])
+def test_gemm1_full_line_loads_do_not_change_a_bit(dev, k, n_norm, tiles, with_fill, coding):
+    """The int8 GEMM 1 with more than three tiles steps over 256 samples = HALF a 128-byte line per row; G1_LINE (default)
+    loads both halves of a line together into a wider register stage (one HBM fetch per line).  Exact int32 accumulation:
+    the same bits as the half-line kernel, at several launch shapes, with fill values, in both genotype codings."""
+    from pyrhe_amd import engine
+    n, m = 30_000, 6000
+    rng = np.random.default_rng(k)
+    packed = engine.synth_genotypes(m, n, 41, 0, dev)
+    fill = None
+    if with_fill:
+        rows = torch.as_tensor(rng.choice(m, 500, replace=False), device=dev)
+        packed[rows, 1000] = (packed[rows, 1000] & 0xF0) | 0x05
+        fill = torch.zeros(m, dtype=torch.float32, device=dev)
+        fill[rows] = torch.as_tensor(rng.integers(0, 3, 500), dtype=torch.float32, device=dev)
+    if coding == "value":
+        packed = engine.recode_rows(packed, "value")
+    lists = [np.sort(rng.choice(m, sz, replace=False)).astype(np.int32) for sz in (2500, 1700)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+    entries = torch.from_numpy(np.concatenate(lists)).to(dev)
+    res = []
+    for opts in ({"g1_line": 0}, {}, {"g1_workgroups": 200}, {"g1_workgroups": 4000, "g1_fill": 0}, {"g1_split_major": 2}):
+        eng = engine.SketchEngine(n, n, max_entries=m, precision="i8x3", device=dev)
+        eng.set_coding(coding)
+        for name, v in opts.items():
+            eng.set_option(name, v)
+        keep = eng.keep_vector([])
+        g = torch.Generator().manual_seed(3)
+        Z = torch.zeros((k, eng.n_pad), device=dev)
+        Z[:, :n] = torch.randn((k, n), generator=g).to(dev)
+        y = torch.zeros((n_norm, eng.n_pad), device=dev)
+        y[:, :n] = torch.randn((n_norm, n), generator=g).to(dev)
+        eng.set_rhs(Z, y, keep)
+        sk, nm, cs = eng.sketch_block(packed, entries, offs, fill=fill, want_colsum=True)
+        torch.cuda.synchronize()
+        assert eng.last_path()["gemm1"] == 100 + tiles
+        res.append([t.clone() for t in (sk, nm, cs)])
+        eng.close()
     for other in res[1:]:
         for a, b in zip(res[0], other):
             assert torch.equal(a, b)
