@@ -271,8 +271,8 @@ def main():
     g1_tiles_i8 = path["gemm1"] % 100
     g1_name = (f"gemm1_i8w_kernel<{g1_tiles_i8}>" if path["gemm1"] >= 200 else f"gemm1_i8_kernel<{g1_tiles_i8}>") if g1_i8 \
         else f"gemm1_kernel<{path['gemm1']}>"
-    g2_packed = path["gemm2"] in (11, 12)
-    g2_name = f"gemm2_i8p_kernel<{path['gemm2'] - 10}>" if g2_packed else "gemm2_kernel"
+    g2_packed = path["gemm2"] in (11, 12, 13)
+    g2_name = ("gemm2_i8p_kernel<2, GV=2>" if path["gemm2"] == 13 else f"gemm2_i8p_kernel<{path['gemm2'] - 10}>") if g2_packed else "gemm2_kernel"
     dom_name = g2_name if dom == "gemm2_kernel" else g1_name
     bytes_per_launch = local_snps * row_bytes / launches                    # algorithmic bytes: ceil(N/4) per SNP
     achieved = bytes_per_launch / (dom_ms / launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -306,7 +306,7 @@ def main():
     tiles_out = max(1, (engine.n_sketch + 15) // 16)
     rows_per_launch = local_snps / launches
     if dom == "gemm2_kernel" and g2_packed:
-        mfma_ops = rows_per_launch * 2.0 * n_pad * 16 * (2 if path["gemm2"] == 11 else 4)      # packed tiles of (digit, column) rows
+        mfma_ops = rows_per_launch * 2.0 * n_pad * 16 * {11: 2, 12: 4, 13: 6}[path["gemm2"]]      # packed tiles of (digit, column) rows
         mfma_peak = 5000.0                                                                     # int8 dense TOP/s
     elif dom == "gemm2_kernel":
         parts = 1 if args.precision in ("f16", "f16e", "i8f16") else 2

@@ -287,7 +287,7 @@ int pyrhe_synth_genotypes(uint8_t* packed, int64_t n_rows, int64_t pitch, int64_
  * which kernels the LAST sketch call launched (so a parity test can assert the path it checked is the path it meant):
  *   6 GEMM 1: 100 + tiles for gemm1_i8_kernel<tiles>, 200 + tiles for gemm1_i8w_kernel<tiles>, tiles for gemm1_kernel<tiles>
  *             (fp16), 0 before any call
- *   7 GEMM 2: 11 / 12 gemm2_i8p_kernel<NG = 1 / 2>, 1 gemm2_kernel (fp16 hi+lo or single), 0 none (no sketch columns)
+ *   7 GEMM 2: 11 / 12 gemm2_i8p_kernel<NG = 1 / 2>, 13 gemm2_i8p_kernel<2, GV = 2> (additive + dominance in one launch), 1 gemm2_kernel (fp16 hi+lo or single), 0 none (no sketch columns)
  *   8 flow  : 1 segmented (one GEMM 1 over the concatenated lists, GEMM 2 by segment), 0 one kernel triple per list
  *   9 merge : segments per workgroup of the last gemm2_i8p_kernel launch (> 1: short lists shared workgroups, PYRHE_OPT_G2_MERGE) */
 int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
@@ -330,6 +330,9 @@ int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
                                       (four waves per SIMD).  Pass 2 at 8 bins + covariates, N = 500k: 9.3 / 8.2 / 12.7 ms        */
 #define PYRHE_OPT_G1_LINE 15       /* int8 GEMM 1 with more than three tiles (256-sample steps): 1 (default) a register stage holds both
                                       halves of a 128-byte line, loaded together; 0 = 64 bytes per row and step                  */
+#define PYRHE_OPT_DOM_FUSE 16      /* dominance outputs in the segmented flow, <= 10 sketch columns: 1 (default) ONE second contraction
+                                      for both estimates (one read of the genotypes: additive and dominance operand tiles side by
+                                      side, the 2 [g == 2] view from the same unpacked bytes); 0 = three launches                  */
 int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t value);
 
 /* name + average device time (ms, from hipEvents on the launch stream) of the kernels of the last

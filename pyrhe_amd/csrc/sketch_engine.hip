@@ -121,8 +121,8 @@ struct pyrhe_engine {
     // dominance (RHE_DOM) extras, allocated on first use: one zeroed region (P2 | wmax2) + vsq2, W2, cmu, zeros
     uint8_t* dom_ws = nullptr;
     size_t dom_zero_bytes = 0, dom_wmax_off = 0;
-    float *P2 = nullptr, *Wtmp2 = nullptr, *cmu = nullptr, *zcoef = nullptr, *vcross2 = nullptr;
-    uint32_t* wmax2 = nullptr;
+    float *P2 = nullptr, *Wtmp2 = nullptr, *cmu = nullptr, *zcoef = nullptr, *vcross2 = nullptr, *W1d = nullptr;
+    uint32_t *wmax2 = nullptr, *wmax1d = nullptr;
     double* vsq2 = nullptr;
     hipStream_t sA = nullptr, sB = nullptr;
     hipEvent_t evIn = nullptr, evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, evDoneA = nullptr, evDoneB = nullptr;
@@ -152,7 +152,7 @@ struct pyrhe_engine {
     }
     size_t total_bytes = 0;
     // launch-shape knobs (pyrhe_engine_set_option); every value computes the same results
-    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1, opt_list_span = 0, opt_g1_fill = 1, opt_dom_seg = 1, opt_dots_f32 = 2, opt_dots_tiles = 2, opt_g1_line = 1, n_cu = 0;
+    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1, opt_list_span = 0, opt_g1_fill = 1, opt_dom_seg = 1, opt_dots_f32 = 2, opt_dots_tiles = 2, opt_g1_line = 1, opt_dom_fuse = 1, n_cu = 0;
     // kernels of the last sketch call (pyrhe_engine_info 6..8)
     int last_g1 = 0, last_g2 = 0, last_flow = 0, last_g2_merged = 0;
 #ifdef PYRHE_DIAG
@@ -516,10 +516,12 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
         const size_t oP2 = carve(S * nc * sizeof(float) * (e->i8 ? 3 : 1));
         const size_t oWm = carve((size_t)kMaxSeg * kSegCols * sizeof(uint32_t));       // per segment (segmented flow), slot 0 otherwise
+        const size_t oWm1 = carve((size_t)kMaxSeg * kSegCols * sizeof(uint32_t));      // maxima of W1 when all three operands live at once (fused GEMM 2)
         e->dom_zero_bytes = off;
         e->dom_wmax_off = oWm;
         const size_t oNa = carve(S * PYRHE_MAX_COLS * sizeof(double));
         const size_t oW2 = carve(S * nc * sizeof(float));
+        const size_t oW1 = carve(S * kI8pCols * sizeof(float));
         const size_t oCm = carve(S * sizeof(float));
         const size_t oZc = carve(S * sizeof(float));
         const size_t oVc2 = carve(S * PYRHE_MAX_COLS * sizeof(float));
@@ -529,6 +531,8 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         e->wmax2 = (uint32_t*)(e->dom_ws + oWm);
         e->vsq2 = (double*)(e->dom_ws + oNa);
         e->Wtmp2 = (float*)(e->dom_ws + oW2);
+        e->W1d = (float*)(e->dom_ws + oW1);
+        e->wmax1d = (uint32_t*)(e->dom_ws + oWm1);
         e->cmu = (float*)(e->dom_ws + oCm);
         e->zcoef = (float*)(e->dom_ws + oZc);
         e->vcross2 = (float*)(e->dom_ws + oVc2);
@@ -876,7 +880,13 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 if (e->n_cross)
                     cross_reduce_kernel<<<tab.nseg * (e->n_cross * (e->n_cross + 1) / 2), 256, 0, stream>>>(e->vcross, e->n_cross, out_cross, tab);
             }
-            if (e->n_sketch) {
+            // RHE_DOM: additive and dominance sketch from ONE read of the genotypes in the second contraction too (round 3:
+            // gemm2_i8p_kernel<2, .., GV = 2> over the six-tile image [Wa | W1 | W2] instead of three launches, the third
+            // read-modify-write)
+            const bool dom_fuse = dom && g2p_dom && e->opt_dom_fuse && e->n_sketch >= 1;
+            if (dom_fuse) {
+                if (e->n_norm) norm_reduce_kernel<<<tab.nseg * e->n_norm, 256, 0, stream>>>(e->vsq, e->n_norm, out_norm, tab);
+            } else if (e->n_sketch) {
                 const int rc = run_gemm2(0, e->Wtmp, e->mu, e->wmax, n, kb, out_sketch, false, set, rows, e->n_norm ? e->vsq : nullptr,
                                          e->n_norm ? out_norm : nullptr, tab, true);
                 if (rc) return rc;
@@ -888,7 +898,35 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                     HIPCHK(hipStreamWaitEvent(sB2, e->evA[set], 0));
                 }
             }
-            if (dom) {
+            if (dom_fuse) {
+                {
+                    ProfScope ps(e, stream, 1);
+                    mid_dom1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->P2, pscale, 1, n, ncol_p, e->n_sketch, e->n_norm, e->rscale,
+                                                                         e->csum, (float)e->n_keep, e->cmu, e->W1d, e->Wtmp2, e->wmax1d, e->wmax2,
+                                                                         e->vsq2, e->n_cross, e->vcross2, e->nd2, e->nd3, tab);
+                    if (e->n_cross)
+                        cross_reduce_kernel<<<tab.nseg * (e->n_cross * (e->n_cross + 1) / 2), 256, 0, stream>>>(e->vcross2, e->n_cross, cross_dom, tab);
+                    if (e->n_norm) norm_reduce_kernel<<<tab.nseg * e->n_norm, 256, 0, stream>>>(e->vsq2, e->n_norm, norm_dom, tab);
+                    const unsigned gridm = (unsigned)(((int64_t)(kb / 2) * 6 * 64 + 255) / 256);
+                    mid2_i8p_dom_kernel<<<gridm, 256, 0, stream>>>(e->Wtmp, e->W1d, e->Wtmp2, e->mu, e->cmu, e->n_sketch, e->wmax, e->wmax1d,
+                                                                  e->wmax2, (int4v*)e->wfrag, e->corr, e->wscale, rows, e->rows32, tab);
+                }
+                SegTab ptab = tab;
+                size_t lds = 0;
+                for (int g = 0; g < tab.nseg; ++g) {
+                    ptab.grp0[g] = (unsigned char)g;
+                    ptab.grp1[g] = (unsigned char)(g + 1);
+                    lds = std::max(lds, g2p_lds(tab.kb0[g + 1] - tab.kb0[g], 1, 2));
+                }
+                e->last_g2 = 13;
+                e->last_g2_merged = 1;
+                ProfScope ps(e, sB2, 2);
+                dim3 grid((unsigned)((e->n_pad + 1023) / 1024 * 2), tab.nseg);
+#define L2F(MISS_, VC_) gemm2_i8p_kernel<2, MISS_, VC_, 2, false><<<grid, 256, lds, sB2>>>(packed, e->pitch, e->rows32, fill, (const int4v*)e->wfrag, e->corr, e->wscale, e->keep, e->n_sketch, e->n_pad, out_sketch, ptab, out_dom)
+                if (e->vc) { if (fill) L2F(true, true); else L2F(false, true); }
+                else { if (fill) L2F(true, false); else L2F(false, false); }
+#undef L2F
+            } else if (dom) {
                 // dominance (rhe_dom.py:15-41; see mid_dom1_kernel): W1 for the G view, W2 for the 2 [g == 2] view, per segment
                 HIPCHK(hipMemsetAsync(e->ws + e->zero_tail, 0, e->zero_bytes - e->zero_tail, stream));      // wmax | corr of every segment
                 {
@@ -1076,6 +1114,7 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
         case PYRHE_OPT_G1_FILL: e->opt_g1_fill = value != 0; break;
         case PYRHE_OPT_G1_LINE: e->opt_g1_line = value != 0; break;
         case PYRHE_OPT_DOM_SEG: e->opt_dom_seg = value != 0; break;
+        case PYRHE_OPT_DOM_FUSE: e->opt_dom_fuse = value != 0; break;
         case PYRHE_OPT_DOTS_TILES:
             if (value != 1 && value != 2 && value != 4) return fail(PYRHE_EINVAL, "DOTS_TILES takes 1, 2 or 4");
             e->opt_dots_tiles = (int)value; break;

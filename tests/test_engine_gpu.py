@@ -458,8 +458,8 @@ def test_loo_dots_multi_equals_separate_calls(dev, nx, nys, nyf, n_sub, batch, w
 @pytest.mark.parametrize("coding,with_fill", [("value", False), ("plink", True), ("value", True)])
 def test_large_cohort_paths_int8_vs_fp16(dev, coding, with_fill):
     """At >= 196608 samples the int8 engine takes paths the small fixtures never reach: a single list through the
-    segmented flow (packed int8 GEMM 2) and RHE_DOM's three GEMM 2 launches on the packed kernel under both genotype
-    views, lists cut into 16384-entry pieces.  Same inputs through the fp16 hi+lo engine (other kernels in every stage):
+    segmented flow (packed int8 GEMM 2) and RHE_DOM's second contraction on the packed kernel under both genotype views -- one
+    fused launch for both estimates (default) or three launches (dom_fuse = 0) --, lists cut into 16384-entry pieces.  Same inputs through the fp16 hi+lo engine (other kernels in every stage):
     additive and dominance sketches and norms agree to 1e-5 of the largest entry."""
     from pyrhe_amd import engine
     n, m, k = 200_000, 18_000, 10
@@ -476,9 +476,11 @@ def test_large_cohort_paths_int8_vs_fp16(dev, coding, with_fill):
     lst = np.sort(rng.choice(m, 17_000, replace=False)).astype(np.int32)       # > 16384: two pieces, the second accumulates
     entries = torch.from_numpy(lst).to(dev)
     outs = {}
-    for precision in ("i8x3", "f16x2"):
-        eng = engine.SketchEngine(n, n, max_entries=m, precision=precision, device=dev)
+    for precision in ("i8x3", "i8x3-unfused", "f16x2"):
+        eng = engine.SketchEngine(n, n, max_entries=m, precision=precision.split("-")[0], device=dev)
         eng.set_coding(coding)
+        if precision == "i8x3-unfused":
+            eng.set_option("dom_fuse", 0)
         keep = eng.keep_vector([])
         g = torch.Generator().manual_seed(4)
         Z = torch.zeros((k, eng.n_pad), device=dev)
@@ -489,13 +491,21 @@ def test_large_cohort_paths_int8_vs_fp16(dev, coding, with_fill):
         sk, nm, _ = eng.sketch_block(packed, entries, [0, len(lst)], fill=fill)
         a, na, d, nd = eng.sketch_block_dom(packed, entries, [0, len(lst)], fill=fill)
         torch.cuda.synchronize()
+        if precision.startswith("i8x3"):       # one second contraction for both estimates (round 3), or three launches
+            assert eng.last_path()["gemm2"] == (13 if precision == "i8x3" else 11)
         outs[precision] = [t.clone() for t in (sk, nm, a, na, d, nd)]
         eng.close()
     # 17 000 SNPs per sum: the fp16 engine accumulates them in float32 (a few 1e-6 of the largest entry), the int8 engine in
     # exact int32 -- the bound here is the parity bound, not the 2e-6 of the short lists above
     for x, r in zip(outs["i8x3"], outs["f16x2"]):
         assert (x - r).abs().max().item() <= 1e-5 * r.abs().max().item()
-    assert torch.equal(outs["i8x3"][0], outs["i8x3"][2])          # the additive sketch of the dominance call is the same kernel path
+    # the additive sketch of the dominance call: the same digits, the same exact int32 sums and the same epilogue arithmetic in
+    # the fused kernel (additive tiles beside the dominance tiles), in the three-launch form the same kernel path
+    assert torch.equal(outs["i8x3"][0], outs["i8x3"][2])
+    assert torch.equal(outs["i8x3-unfused"][0], outs["i8x3-unfused"][2])
+    # fused against three launches: W1 and W2 share one digit scale per column in the fused form (24-bit digits either way)
+    for x, r in zip(outs["i8x3"], outs["i8x3-unfused"]):
+        assert (x - r).abs().max().item() <= 1e-6 * r.abs().max().item()
 
 
 def test_pipelined_streams_equal_serial(dev):

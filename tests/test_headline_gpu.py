@@ -234,18 +234,19 @@ def test_genie_gxe_covariates_one_wide_pass_vs_oracle():
 
 def test_rhe_dom_segmented_flow_at_n200k_vs_oracle():
     """RHE_DOM through the segmented flow (round 3): three blocks in ONE engine call -- one GEMM 1 launch for both genotype views
-    (gemm1_i8_kernel<3, .., GV = 2>), then three packed GEMM 2 launches over all segments (additive, dominance under the G view,
-    dominance under the 2 [g == 2] view) instead of three per list (rhe_dom.py:15-41, streaming_rhe_dom.py:9-68).  Additive and
+    (gemm1_i8_kernel<3, .., GV = 2>), then ONE packed GEMM 2 launch over all segments for both estimates (gemm2_i8p_kernel<2, ..,
+    GV = 2>: additive tiles, dominance tiles under the G view and under the 2 [g == 2] view from one read of the genotypes;
+    rhe_dom.py:15-41, streaming_rhe_dom.py:9-68).  Additive and
     dominance sketches and norms per block, sigma^2 and SE against the oracle."""
     p, runner, engs = _setup(200_000, 384, 3, 10, row0=37, dom=True)
-    _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3)
+    _check(p, runner, engs, {"gemm1": 103, "gemm2": 13, "segmented": True}, blocks_per_call=3)
 
 
 def test_rhe_dom_bins_and_covariates_segmented_at_n200k_vs_oracle():
     """The same with 2 bins and 5 covariates as cross columns under BOTH encodings (S and S_dom per block and bin)."""
     p, runner, engs = _setup(200_000, 384, 3, 10, nbin=2, n_cov=5, row0=41, dom=True)
     assert runner.cross and runner.cross_digits == 1         # 10 x 3 + 3 + 5 + 1 = 39 packed digit rows: three tiles
-    _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3, with_exact=False)
+    _check(p, runner, engs, {"gemm1": 103, "gemm2": 13, "segmented": True}, blocks_per_call=3, with_exact=False)
 
 
 def test_blocks_beyond_one_call_are_split_into_row_pieces():
