@@ -38,6 +38,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
+#include <type_traits>
 
 #include "../../include/pyrhe_sketch.h"
 #include "sketch_common.h"
@@ -111,6 +112,8 @@ struct pyrhe_engine {
     size_t partial_bytes = 0;
     double* dots_partial = nullptr;   // workgroup partials of pyrhe_engine_loo_dots (allocated on first use)
     size_t dots_partial_bytes = 0;
+    float* dots_y32 = nullptr;        // float32 copies of the fixed rows of pyrhe_engine_loo_dots_multi (float32 form)
+    size_t dots_y32_bytes = 0;
     // Two workspace sets + two internal streams: GEMM 1 (+ mid) of sub-block g+1 runs on stream A while GEMM 2 of
     // sub-block g runs on stream B -- a DRAM-pattern-bound kernel beside an instruction-bound one.  The members
     // above alias the set in use (kernel arguments are captured by value at launch).
@@ -302,7 +305,7 @@ extern "C" int pyrhe_engine_destroy(pyrhe_engine_t* e) {
     if (e->evIn) (void)hipEventDestroy(e->evIn);
     if (e->evDoneA) (void)hipEventDestroy(e->evDoneA);
     if (e->evDoneB) (void)hipEventDestroy(e->evDoneB);
-    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->partial); hipFree(e->dom_ws); hipFree(e->dots_partial);
+    hipFree(e->keepmask); hipFree(e->keep); hipFree(e->partial); hipFree(e->dom_ws); hipFree(e->dots_partial); hipFree(e->dots_y32);
     delete e;
     return PYRHE_OK;
 }
@@ -1367,6 +1370,33 @@ extern "C" int pyrhe_engine_loo_dots_multi(pyrhe_engine_t* e, const pyrhe_row_t*
         Ys.p[c] = c < ny_sub ? y_sub[c].tot : nullptr;
         Yf.p[c] = c < ny_flat ? y_flat[c].tot : nullptr;
     }
+    const bool dots_f32 = e->opt_dots_f32 == 1 || (e->opt_dots_f32 == 2 && period >= 65536);
+    if (dots_f32) {
+        // the float32 form reads float32 COPIES of the fixed rows (made here, once per call: the rows change between calls)
+        FixedRows32Src src;
+        int64_t total = 0, longest = 0;
+        for (int c = 0; c < ny_sub + ny_flat; ++c) {
+            const int64_t len = c < ny_sub ? (int64_t)n_sub * period : period;
+            src.p[c] = c < ny_sub ? y_sub[c].tot : y_flat[c - ny_sub].tot;
+            src.len[c] = len;
+            src.off[c] = total;
+            total += len;
+            longest = std::max(longest, len);
+        }
+        if (e->dots_y32_bytes < (size_t)total * sizeof(float)) {
+            if (e->dots_y32) {
+                HIPCHK(hipDeviceSynchronize());
+                HIPCHK(hipFree(e->dots_y32));
+                e->dots_y32 = nullptr;
+                e->dots_y32_bytes = 0;
+            }
+            HIPCHK(hipMalloc(&e->dots_y32, (size_t)total * sizeof(float)));
+            e->dots_y32_bytes = (size_t)total * sizeof(float);
+        }
+        fixed_rows_f32_kernel<<<dim3((unsigned)std::min<int64_t>(1024, (longest / 4 + 255) / 256), (unsigned)(ny_sub + ny_flat)), 256, 0, stream>>>(src, e->dots_y32);
+        for (int c = 0; c < ny_sub; ++c) Ys.p[c] = reinterpret_cast<const double*>(e->dots_y32 + src.off[c]);
+        for (int c = 0; c < ny_flat; ++c) Yf.p[c] = reinterpret_cast<const double*>(e->dots_y32 + src.off[ny_sub + c]);
+    }
     // two tiles (32 block rows) per wave, two waves per SIMD (PYRHE_OPT_DOTS_TILES = 2, the default) or four tiles per wave
     const int tpw = e->opt_dots_tiles, cpw = tpw;      // tiles per wave = chunks per workgroup (1, 2 or 4)
     const int64_t ncgs = ((n_chunks + cpw - 1) / cpw) * (int64_t)n_sub;      // (chunk group, sub-row) pieces of the fixed rows
@@ -1374,7 +1404,6 @@ extern "C" int pyrhe_engine_loo_dots_multi(pyrhe_engine_t* e, const pyrhe_row_t*
     // float32 matrix instruction with 128-element float32 partial sums (PYRHE_OPT_DOTS_F32): automatic from 65 536 samples on,
     // where a row holds >= 512 such partial sums and the float64 sum over them averages their rounding (measured at N = 500k:
     // sigma^2 unchanged to 16 digits, jackknife SEs 5e-9; tools/r3_dots_f32.sh); small cohorts, which gain nothing, stay float64
-    const bool dots_f32 = e->opt_dots_f32 == 1 || (e->opt_dots_f32 == 2 && period >= 65536);
 #define LMK(F_, S_, X_, T_) blk_multi_dots_kernel<F_, S_, X_, T_><<<grid, 256, 0, stream>>>(tab, nx, nxp, n_batch, Ys, ny_sub, Yf, ny_flat, period, chunk, (int)n_chunks, n_sub, rgs, ps, pf, pg)
 #define LM(F_, S_) do { if (dots_f32) { if (tpw == 1) LMK(F_, S_, true, 1); else if (tpw == 2) LMK(F_, S_, true, 2); else LMK(F_, S_, true, 4); } \
                         else { if (tpw == 1) LMK(F_, S_, false, 1); else if (tpw == 2) LMK(F_, S_, false, 2); else LMK(F_, S_, false, 4); } } while (0)
