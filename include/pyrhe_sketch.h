@@ -333,6 +333,9 @@ int64_t pyrhe_engine_info(const pyrhe_engine_t* e, int what);
 #define PYRHE_OPT_DOM_FUSE 16      /* dominance outputs in the segmented flow, <= 10 sketch columns: 1 (default) ONE second contraction
                                       for both estimates (one read of the genotypes: additive and dominance operand tiles side by
                                       side, the 2 [g == 2] view from the same unpacked bytes); 0 = three launches                  */
+#define PYRHE_OPT_G1_COMPACT 17    /* 128-row int8 GEMM 1 whose last operand tile has at most two live digit rows (10 probes + 1 phenotype:
+                                      34 rows): 1 (default) those rows are staged from a compact copy of the tile, one LDS-DMA per
+                                      step instead of eight; 0 = the tile is staged like the others                               */
 int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t value);
 
 /* name + average device time (ms, from hipEvents on the launch stream) of the kernels of the last

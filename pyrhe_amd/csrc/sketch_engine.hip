@@ -112,6 +112,7 @@ struct pyrhe_engine {
     size_t partial_bytes = 0;
     double* dots_partial = nullptr;   // workgroup partials of pyrhe_engine_loo_dots (allocated on first use)
     size_t dots_partial_bytes = 0;
+    const void* rimg_compact = nullptr;   // compact last tile of the int8 operand image (set_rhs), or NULL
     float* dots_y32 = nullptr;        // float32 copies of the fixed rows of pyrhe_engine_loo_dots_multi (float32 form)
     size_t dots_y32_bytes = 0;
     // Two workspace sets + two internal streams: GEMM 1 (+ mid) of sub-block g+1 runs on stream A while GEMM 2 of
@@ -155,7 +156,7 @@ struct pyrhe_engine {
     }
     size_t total_bytes = 0;
     // launch-shape knobs (pyrhe_engine_set_option); every value computes the same results
-    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1, opt_list_span = 0, opt_g1_fill = 1, opt_dom_seg = 1, opt_dots_f32 = 2, opt_dots_tiles = 2, opt_g1_line = 1, opt_dom_fuse = 1, n_cu = 0;
+    int opt_g1_wgs = 1536, opt_g2_packed = 1, opt_g2_iw = 0, opt_g2_splits = 0, opt_dots_generic = 0, opt_g1_split_major = 0, opt_g1_wide = 1, opt_g2_merge = 1536, opt_g1_zero_rows = 1, opt_list_span = 0, opt_g1_fill = 1, opt_dom_seg = 1, opt_dots_f32 = 2, opt_dots_tiles = 2, opt_g1_line = 1, opt_dom_fuse = 1, opt_g1_compact = 1, n_cu = 0;
     // kernels of the last sketch call (pyrhe_engine_info 6..8)
     int last_g1 = 0, last_g2 = 0, last_flow = 0, last_g2_merged = 0;
 #ifdef PYRHE_DIAG
@@ -392,6 +393,16 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
             const int64_t th = (e->n_pad / 256) * 4 * e->nt8 * 64;
             prep_rimg_i8_kernel<<<(unsigned)((th + 255) / 256), 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->nd2, e->nd3, e->nt8, e->colmax, e->rscale,
                                                                               (int4v*)e->rfrag, e->csum);
+            // at most two live rows in the last of two or three tiles (the headline's 34 digit rows): a compact copy of that tile
+            // behind the image for gemm1_i8w_kernel<.., CL> (2 bytes per sample; the image buffer is sized for kMaxTiles tiles)
+            e->rimg_compact = nullptr;
+            const int live_last_rows = e->nslots - 16 * (e->nt8 - 1);
+            if (e->nt8 >= 2 && e->nt8 <= 3 && live_last_rows <= 2 && (size_t)e->n_pad * (16 * e->nt8 + 2) <= e->rfrag_bytes) {
+                int4v* comp = (int4v*)e->rfrag + (size_t)e->n_pad * e->nt8;          // the image holds n_pad * nt8 int4v
+                const int64_t n_steps = e->n_pad / 512, thc = n_steps * 64;
+                prep_rimg_i8_compact_kernel<<<(unsigned)((thc + 255) / 256), 256, 0, stream>>>((const int4v*)e->rfrag, e->nt8, n_steps, comp);
+                e->rimg_compact = comp;
+            }
         } else if (e->parts == 2)
             prep_rfrag_kernel<2, true><<<grid, 256, 0, stream>>>(R, e->keep, e->n_pad, n_cols, e->ntl, e->colmax, e->rscale, e->rfrag, e->csum);
         else if (e->exact)
@@ -616,6 +627,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
 #endif
         e->last_g1 = e->i8 ? (wide ? 200 : 100) + e->nt8 : e->ntl;
         const int live_last = e->opt_g1_zero_rows ? e->nslots - 16 * (e->nt8 - 1) : 16;     // live digit rows of the last int8 tile
+        const bool compact = wide && e->opt_g1_compact && e->rimg_compact && e->nslots - 16 * (e->nt8 - 1) <= 2;   // gemm1_i8w_kernel<.., CL>
         if (e->i8) {
             const size_t lds = (size_t)2 * g1_ch * 4 * e->nt8 * 1024;
 #define G1A (packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, (int*)Pbuf2, sm, g1_diag, live_last)
@@ -623,8 +635,11 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                                                         else gemm1_i8_kernel<NT_, MISS_, GV_, false, 4, (NT_ > 3 && GV_ != 2)><<<grid, 256, lds, stream>>>G1A; } \
                                   else if (e->vc) gemm1_i8_kernel<NT_, MISS_, GV_, true><<<grid, 256, lds, stream>>>G1A; \
                                   else gemm1_i8_kernel<NT_, MISS_, GV_, false><<<grid, 256, lds, stream>>>G1A; } while (0)
-#define G1X(NT_, MISS_) do { if (e->vc) gemm1_i8w_kernel<NT_, MISS_, true><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, sm, live_last); \
-                             else gemm1_i8w_kernel<NT_, MISS_, false><<<grid, 256, lds, stream>>>(packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, sm, live_last); } while (0)
+#define G1XA (packed, e->pitch, rows, n, fill, (const int4v*)e->rfrag, n_steps, cps, (int*)Pbuf, ua, sm, live_last, (const int4v*)e->rimg_compact)
+#define G1X(NT_, MISS_) do { if (compact && NT_ >= 2 && NT_ <= 3) { if (e->vc) gemm1_i8w_kernel<NT_, MISS_, true, 4, (NT_ >= 2 && NT_ <= 3)><<<grid, 256, lds + 4096, stream>>>G1XA; \
+                                                                      else gemm1_i8w_kernel<NT_, MISS_, false, 4, (NT_ >= 2 && NT_ <= 3)><<<grid, 256, lds + 4096, stream>>>G1XA; } \
+                             else if (e->vc) gemm1_i8w_kernel<NT_, MISS_, true><<<grid, 256, lds, stream>>>G1XA; \
+                             else gemm1_i8w_kernel<NT_, MISS_, false><<<grid, 256, lds, stream>>>G1XA; } while (0)
 #define G1J(NT_) do { if (wide) { if (fill) G1X(NT_, true); else G1X(NT_, false); break; } if (gv == 0) { if (fill) G1I(NT_, true, 0); else G1I(NT_, false, 0); } \
                       else if (gv == 1) { if (fill) G1I(NT_, true, 1); else G1I(NT_, false, 1); } \
                       else { if (fill) G1I(NT_, true, 2); else G1I(NT_, false, 2); } } while (0)
@@ -638,6 +653,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             }
 #undef G1J
 #undef G1X
+#undef G1XA
 #undef G1I
 #undef G1A
         } else {
@@ -1118,6 +1134,7 @@ extern "C" int pyrhe_engine_set_option(pyrhe_engine_t* e, int option, int64_t va
         case PYRHE_OPT_G1_LINE: e->opt_g1_line = value != 0; break;
         case PYRHE_OPT_DOM_SEG: e->opt_dom_seg = value != 0; break;
         case PYRHE_OPT_DOM_FUSE: e->opt_dom_fuse = value != 0; break;
+        case PYRHE_OPT_G1_COMPACT: e->opt_g1_compact = value != 0; break;
         case PYRHE_OPT_DOTS_TILES:
             if (value != 1 && value != 2 && value != 4) return fail(PYRHE_EINVAL, "DOTS_TILES takes 1, 2 or 4");
             e->opt_dots_tiles = (int)value; break;

@@ -167,7 +167,7 @@ def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28, r
 
 CODINGS = {"plink": 0, "value": 1}
 # PYRHE_OPT_* of include/pyrhe_sketch.h: launch-shape knobs, every value computes the same results
-OPTIONS = {"g1_workgroups": 1, "g2_packed": 2, "g2_iw": 3, "g2_splits": 4, "dots_generic": 5, "g1_split_major": 6, "g1_wide": 7, "g2_merge": 8, "g1_zero_rows": 9, "list_span": 10, "g1_fill": 11, "dom_seg": 12, "dots_f32": 13, "dots_tiles": 14, "g1_line": 15, "dom_fuse": 16,
+OPTIONS = {"g1_workgroups": 1, "g2_packed": 2, "g2_iw": 3, "g2_splits": 4, "dots_generic": 5, "g1_split_major": 6, "g1_wide": 7, "g2_merge": 8, "g1_zero_rows": 9, "list_span": 10, "g1_fill": 11, "dom_seg": 12, "dots_f32": 13, "dots_tiles": 14, "g1_line": 15, "dom_fuse": 16, "g1_compact": 17,
            "diag_g1_plain_store": 100, "diag_g1_no_barrier": 101, "diag_g1_stats": 102}     # 100+: only in the diagnostic build (PYRHE_LIB=...libpyrhe_sketch_diag.so), wrong results
 
 

@@ -593,7 +593,8 @@ def test_merged_segments_equal_one_segment_per_workgroup(dev, k, with_fill, codi
 def test_gemm1_launch_shape_options_do_not_change_a_bit(dev):
     """The int8 GEMM 1 accumulates in exact int32 (integer atomics across the sample splits), so every launch shape gives the
     same bits: workgroup target (G1_WORKGROUPS), round-filling choice of the split count (G1_FILL), 64- or 128-row kernel
-    (G1_WIDE), grid order (G1_SPLIT_MAJOR), shared zero rows of the last operand tile (G1_ZERO_ROWS)."""
+    (G1_WIDE), grid order (G1_SPLIT_MAJOR), shared zero rows of the last operand tile (G1_ZERO_ROWS), the last tile's two live
+    rows (10 probes + 1 phenotype = 34 digit rows) staged from the compact copy or like the other tiles (G1_COMPACT)."""
     from pyrhe_amd import engine
     n, m, k = 40_000, 24_000, 10
     rng = np.random.default_rng(77)
@@ -604,7 +605,8 @@ def test_gemm1_launch_shape_options_do_not_change_a_bit(dev):
     res, paths = [], set()
     for opts in ({}, {"g1_fill": 0}, {"g1_workgroups": 300}, {"g1_workgroups": 5000}, {"g1_wide": 0}, {"g1_wide": 2},
                  {"g1_wide": 2, "g1_workgroups": 700, "g1_split_major": 1}, {"g1_zero_rows": 0},
-                 {"g1_split_major": 2}, {"g1_wide": 0, "g1_split_major": 2, "g1_workgroups": 1000}):
+                 {"g1_split_major": 2}, {"g1_wide": 0, "g1_split_major": 2, "g1_workgroups": 1000},
+                 {"g1_compact": 0}, {"g1_compact": 0, "g1_wide": 2, "g1_workgroups": 900}):
         eng = engine.SketchEngine(n, n, max_entries=m, precision="i8x3", device=dev, sub_snps=32768)
         eng.set_coding("value")
         for name, v in opts.items():
