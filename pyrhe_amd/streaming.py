@@ -462,8 +462,8 @@ class SketchRunner:
         return max(1, min(by_entries, by_bytes, by_lists))
 
     def _dom_batches(self) -> bool:
-        """RHE_DOM through the engine's segmented flow (several blocks per call, three GEMM 2 launches per call instead of per
-        list): the int8 engine with both genotype views in one GEMM 1 launch (<= 4 tiles) and, for single-bin cohorts, the
+        """RHE_DOM through the engine's segmented flow (several blocks per call; one fused GEMM 2 launch per call -- three with
+        dom_fuse = 0 -- instead of three per list): the int8 engine with both genotype views in one GEMM 1 launch (<= 4 tiles) and, for single-bin cohorts, the
         packed GEMM 2 (<= 10 sketch columns, >= 192k samples) -- the engine's own rule (sketch_impl: dom_seg)."""
         if not hasattr(self, "n_pass"):
             return False
