@@ -164,8 +164,8 @@ def test_headline_kernels_at_n500k_vs_oracle():
 
 def test_headline_kernels_at_n500k_narrow_gemm1_vs_oracle():
     """The 64-rows-per-wave GEMM 1 (`g1_wide = 0`; what cohorts below 196 608 samples and four or more tiles run) at the same
-    size: both int8 GEMM 1 kernels are held to the oracle at N = 500 000."""
-    p, runner, engs = _setup(500_000, 600, 3, 10, row0=1000)
+    cohort size (three 128-SNP blocks): both int8 GEMM 1 kernels are held to the oracle at N = 500 000."""
+    p, runner, engs = _setup(500_000, 384, 3, 10, row0=1000)
     for e_ in engs:
         e_.set_option("g1_wide", 0)
     _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3)
