@@ -609,6 +609,13 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 const double r = (double)wgs / slots, fill = r / std::ceil(r);
                 if (fill > best + 1e-9) { best = fill; splits = s2; cps = c; }
             }
+            // Short rows (<= 128 steps: cohorts up to 65 536 samples) whose row groups alone fill ONE round of the resident slots --
+            // a full call of such a cohort: 262 144 entries = 512 groups of 512 rows -- take no sample split at all: a third of the
+            // prologues, plain stores instead of atomics (N = 50k: GEMM 1 1.29-1.36 -> 1.25 ms per pass, tools/r3_s28.sh)
+            if (wide && n_steps <= 128 && gx <= slots && (int64_t)gx * 100 >= (int64_t)slots * 85) {
+                splits = 1;
+                cps = round_cps(n_steps);
+            }
         }
         float* saveP = e->P;
         e->P = Pbuf;

@@ -629,6 +629,36 @@ def test_gemm1_launch_shape_options_do_not_change_a_bit(dev):
             assert torch.equal(a, b)
 
 
+def test_gemm1_full_call_of_a_small_cohort_takes_no_sample_split(dev):
+    """A call whose 512-row groups alone fill one round of the chip's resident workgroups (a small cohort's full call: 262 144
+    entries) runs the 128-row GEMM 1 without sample splits -- plain stores instead of integer atomics.  Same bits as the split
+    launch (`g1_fill = 0`), and as the 64-row kernel."""
+    from pyrhe_amd import engine
+    n, m, k = 20_000, 250_000, 10
+    packed = engine.recode_rows(engine.synth_genotypes(m, n, 5, 0, dev), "value")
+    entries = torch.arange(m, dtype=torch.int32, device=dev)
+    res = []
+    for opts in ({}, {"g1_fill": 0}, {"g1_wide": 0}):
+        eng = engine.SketchEngine(n, n, max_entries=m, precision="i8x3", device=dev, sub_snps=262144)
+        eng.set_coding("value")
+        for name, v in opts.items():
+            eng.set_option(name, v)
+        keep = eng.keep_vector([])
+        g = torch.Generator().manual_seed(8)
+        Z = torch.zeros((k, eng.n_pad), device=dev)
+        Z[:, :n] = torch.randn((k, n), generator=g).to(dev)
+        y = torch.zeros((1, eng.n_pad), device=dev)
+        y[:, :n] = torch.randn((1, n), generator=g).to(dev)
+        eng.set_rhs(Z, y, keep)
+        sk, nm, cs = eng.sketch_block(packed, entries, [0, 100_000, m], want_colsum=True)
+        torch.cuda.synchronize()
+        res.append([t.clone() for t in (sk, nm, cs)])
+        eng.close()
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("k,n_norm,tiles", [(16, 1, 4), (20, 2, 5), (26, 2, 6)])
 @pytest.mark.parametrize("with_fill,coding", [(False, "value"), (True, "value"), (True, "plink")])
 def test_gemm1_full_line_loads_do_not_change_a_bit(dev, k, n_norm, tiles, with_fill, coding):
