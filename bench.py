@@ -352,6 +352,17 @@ def main():
         except Exception as ex:
             out["config"][name] = {"failed": f"{type(ex).__name__}: {ex}"}
 
+    def leg_stream_read():
+        """the box's MEASURED stream bandwidth beside the nominal peak -- a plain 16-bytes-per-lane read of this rank's
+        genotype rows (pyrhe_stream_read, up to 32 GB of them), and the dominant kernel's rate as a fraction of it."""
+        n_rows_s = int(min(geno.shape[0], (32 << 30) // geno.shape[1]))
+        gbs = eng_mod.stream_read_gbs(geno[:n_rows_s])
+        roofline["stream_read"] = {"measured_GBps": round(gbs, 1), "bytes": int(n_rows_s * geno.shape[1]),
+                                   "frac_of_measured": round(achieved / gbs, 4) if gbs > 0 else None,
+                                   "what": "plain linear read, 16 B per lane, four loads in flight (pyrhe_stream_read); best of 3"}
+    if not args.no_alt:
+        extra("stream_read", leg_stream_read)
+
     def leg_end_to_end():     # pass 2 + solves are cheap next to the sketch pass: always timed, reported beside the metric
         w = runner.pass2()                                                  # untimed: scratch allocation, BLAS thread start
         est.solve_all(w.T[:1], w.q[:1])

@@ -282,6 +282,13 @@ int pyrhe_decode_rows(const uint8_t* packed, int64_t n_rows, int64_t pitch, floa
 int pyrhe_synth_genotypes(uint8_t* packed, int64_t n_rows, int64_t pitch, int64_t n_samples,
                           uint64_t seed, int64_t row0, void* stream);
 
+/*
+ * Plain streaming read of `bytes` bytes of device memory (16-byte loads, every byte read once; the xor of the data may be
+ * added to *sink, a device word): the box's measured read-stream bandwidth that bench.py reports beside the nominal HBM peak
+ * (no counterpart in the reference; measurement aid).   Asynchronous on `stream`.
+ */
+int pyrhe_stream_read(const void* buf, int64_t bytes, uint32_t* sink, void* stream);
+
 /* engine introspection: 0 n_pad, 1 sub_snps, 2 n_tiles_in, 3 n_sketch, 4 n_norm, 5 workspace bytes, 10 n_cross,
  * 11 packed (digit, column) rows of the int8 GEMM 1's operand;
  * which kernels the LAST sketch call launched (so a parity test can assert the path it checked is the path it meant):

@@ -1519,6 +1519,14 @@ extern "C" int pyrhe_synth_genotypes(uint8_t* packed, int64_t n_rows, int64_t pi
     return PYRHE_OK;
 }
 
+extern "C" int pyrhe_stream_read(const void* buf, int64_t bytes, uint32_t* sink, void* stream_) {
+    if (!buf || !sink) return fail(PYRHE_EINVAL, "NULL argument");
+    if (bytes <= 0 || bytes % 16 || ((uintptr_t)buf & 15)) return fail(PYRHE_EINVAL, "buffer must be 16-byte aligned and a multiple of 16 bytes");
+    stream_read_kernel<<<4096, 256, 0, (hipStream_t)stream_>>>(reinterpret_cast<const uint4*>(buf), bytes / 16, sink);
+    HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
 extern "C" int pyrhe_engine_profile(pyrhe_engine_t* e, int enable) {
     if (!e) return fail(PYRHE_EINVAL, "NULL engine");
     e->evs.clear();

@@ -52,6 +52,7 @@ SYMBOLS = {
     "pyrhe_engine_loo_dots_multi": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pyrhe_engine_apply_projector": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp]),
     "pyrhe_synth_genotypes": (_i32, [_vp, _i64, _i64, _i64, _u64, _i64, _vp]),
+    "pyrhe_stream_read": (_i32, [_vp, _i64, _vp, _vp]),
     "pyrhe_engine_info": (_i64, [_vp, _i32]),
     "pyrhe_engine_profile": (_i32, [_vp, _i32]),
     "pyrhe_engine_profile_read": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
@@ -180,6 +181,26 @@ def recode_rows(packed: torch.Tensor, to: str = "value") -> torch.Tensor:
         _check(load_library().pyrhe_recode_rows(_ptr(packed), packed.shape[0], packed.shape[1], CODINGS[to],
                                                 _stream_ptr(packed.device)), "pyrhe_recode_rows")
     return packed
+
+
+def stream_read_gbs(buf: torch.Tensor, repeats: int = 3) -> float:
+    """Measured plain read-stream bandwidth (GB/s) over ``buf`` (``pyrhe_stream_read``; best of ``repeats``, HIP events on the
+    current stream)."""
+    lib = load_library()
+    dev = _require_gpu(buf.device)
+    nbytes = buf.numel() * buf.element_size() // 16 * 16
+    sink = torch.zeros(1, dtype=torch.int32, device=dev)
+    best = 0.0
+    with torch.cuda.device(dev):
+        for _ in range(repeats + 1):                      # the first pass is a warm-up
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            _check(lib.pyrhe_stream_read(_ptr(buf), nbytes, _ptr(sink), _stream_ptr(dev)), "pyrhe_stream_read")
+            t1.record()
+            t1.synchronize()
+            if _ > 0:
+                best = max(best, nbytes / (t0.elapsed_time(t1) * 1e-3) / 1e9)
+    return best
 
 
 def synth_genotypes(n_rows: int, n_samples: int, seed: int, row0: int, device, out: Optional[torch.Tensor] = None) -> torch.Tensor:

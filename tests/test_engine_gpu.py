@@ -629,6 +629,16 @@ def test_gemm1_launch_shape_options_do_not_change_a_bit(dev):
             assert torch.equal(a, b)
 
 
+def test_stream_read_measures_a_bandwidth_and_rejects_bad_buffers(dev):
+    """pyrhe_stream_read, bench.py's measuring stick (the box's measured stream bandwidth beside the nominal peak)."""
+    from pyrhe_amd import engine
+    buf = torch.zeros(1 << 28, dtype=torch.uint8, device=dev)
+    gbs = engine.stream_read_gbs(buf)
+    assert 100.0 < gbs < 20000.0                   # a real number: above PCIe rates, below any HBM peak
+    with pytest.raises(engine.SketchError):
+        engine.stream_read_gbs(buf[:8])            # fewer than 16 bytes
+
+
 def test_gemm1_full_call_of_a_small_cohort_takes_no_sample_split(dev):
     """A call whose 512-row groups alone fill one round of the chip's resident workgroups (a small cohort's full call: 262 144
     entries) runs the 128-row GEMM 1 without sample splits -- plain stores instead of integer atomics.  Same bits as the split
