@@ -266,6 +266,7 @@ class SketchRunner:
             self.UZ64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.UZ.T)))  # [k, n_pad]
             self.WT64 = self.W64.T.contiguous()                                              # [c, n_pad]
             self.WT32 = self.WT64.to(torch.float32)
+            self.G64 = torch.from_numpy(self.Q @ (W.T @ self.Z)).to(self.device)             # [c, k]: U Z = W G
         # Covariates: XXUz = X X^T (U Z) enters the normal equations only through sum(XXUz * UXXz) (base.py:589-591) and
         # UXXz lies in span(W), so only W^T XXUz = (W^T X X^T W)(Q W^T Z) is needed: the c covariate columns go through the
         # first contraction as CROSS columns and the engine returns S = W^T X X^T W per (block, bin) -- no U Z sketch
@@ -275,20 +276,19 @@ class SketchRunner:
         self.wide_cols = getattr(self.eng, "precision", "") in ("i8x3", "i8f16")       # int8 engines: up to 46 columns per pass
         self.cross = (self.cov is not None and not materialize_xxuz and
                       cross_columns_pay(self.k, self.cov.shape[1], self.n_gxe > 0, self.cross_digits, self.wide_cols))
-        if self.cross:
-            self.G64 = torch.from_numpy(self.Q @ (self.cov.T @ self.Z)).to(self.device)      # [c, k]: U Z = W G
-            # int8 digits of the covariate columns in the first contraction (PYRHE_COL_DIGITS): S only enters the O(c / N) terms
-            # of T.  Measured on the CPU stand-in (N = 500 / 2000, 6 covariates, 3 bins): two digits move sigma^2 / SE by 4e-8 /
-            # 8e-8 at N = 500; ONE digit by 6e-6 / 1e-5 at N = 500, 2e-7 / 1.6e-6 at N = 2000 (it falls as 1 / N^2: below 3e-8
-            # from N = 16 384 on).  One digit packs 10 probes + phenotype + 10 covariates into 44 digit rows = three tiles (the
-            # 128-row GEMM 1) instead of four: 8 bins + 10 covariates at N = 500k 30.5 -> 23.7 ms per pass in GEMM 1.  S itself
-            # then carries the 1 % quantisation noise of an 8-bit W (exact for an intercept or 0/1 covariates); small cohorts,
-            # where a tile more costs nothing, keep all three digits.  ``cross_digits`` overrides (tests hold S to 2e-5 at 3).
+        # int8 digits of the covariate (cross) columns in the first contraction (PYRHE_COL_DIGITS): S only enters the O(c / N) terms
+        # of T.  Measured on the CPU stand-in (N = 500 / 2000, 6 covariates, 3 bins): two digits move sigma^2 / SE by 4e-8 /
+        # 8e-8 at N = 500; ONE digit by 6e-6 / 1e-5 at N = 500, 2e-7 / 1.6e-6 at N = 2000 (it falls as 1 / N^2: below 3e-8
+        # from N = 16 384 on).  One digit packs 10 probes + phenotype + 10 covariates into 44 digit rows = three tiles (the
+        # 128-row GEMM 1) instead of four: 8 bins + 10 covariates at N = 500k 30.5 -> 23.7 ms per pass in GEMM 1.  S itself
+        # then carries the 1 % quantisation noise of an 8-bit W (exact for an intercept or 0/1 covariates); small cohorts,
+        # where a tile more costs nothing, keep all three digits.  ``cross_digits`` overrides (tests hold S to 2e-5 at 3).
         self.Z64 = self._pad_cols(torch.from_numpy(np.ascontiguousarray(self.Z.T)))        # [k, n_pad] f64
         if self.env is not None:
             self.env_pad = self._pad_cols(torch.from_numpy(self.env[None, :]))[0]            # [n_pad] f64
             self.env32 = self.env_pad.to(torch.float32)
         self.pass2_impl = "hip"       # "torch": materialised cross-check path (tests)
+        self.force_tk_proj = False    # tests: <XXz, U Z> through the covariate projections even where the U Z row has room (_loo_systems)
         self.norm_digits = 3          # int8 digits of the phenotype columns in GEMM 1 (precision experiments: tools/r3_ydigits.sh)
         self.one_slot = False         # this trait group keeps ONE block slot and re-sketches in pass 2 (begin_trait decides)
         self.row_limit = None         # rows one engine call may address; None = from the engine's 32-bit byte offsets
@@ -1161,8 +1161,15 @@ class SketchRunner:
                     torch.zeros((batch, n, n), **f64) if want_self else None)
         live = [rows_blk[i] for i in idx]
         multi = getattr(self.eng, "loo_dots_multi", None)
-        if multi is not None and self.eng.multi_ok(live, y_sub, y_flat, self.n_pad):
+        # more than 16 sub-strided fixed rows (GENIE with 8 bins: 16 estimates + Z): a second pass over the store for the rest
+        y_more = y_sub[16:] if len(y_sub) > 16 else []
+        y_sub = y_sub[:16]
+        if multi is not None and self.eng.multi_ok(live, y_sub, y_flat, self.n_pad) and \
+                (not y_more or self.eng.multi_ok(live, y_more, [], self.n_pad)):
             o_sub, o_flat, o_self = multi(live, y_sub, y_flat, want_self, self.n_pad, nc, batch)
+            if y_more:
+                o_sub = torch.cat([o_sub, multi(live, y_more, [], False, self.n_pad, nc, batch)[0]], dim=2)
+            y_sub = y_sub + y_more
             if len(idx) == n:
                 return o_sub, o_flat, o_self
             ix = torch.as_tensor(idx, device=self.device)
@@ -1176,6 +1183,7 @@ class SketchRunner:
                 b_self = torch.zeros((batch, n, n), **f64)
                 b_self[:, ix[:, None], ix[None, :]] = o_self
             return b_sub, b_flat, b_self
+        y_sub = y_sub + y_more
         b_sub = self._dots(rows_blk, y_sub, nc, batch)
         b_flat = None
         if y_flat:
@@ -1270,7 +1278,11 @@ class SketchRunner:
             fixed = list(A_tot)
             if self.genie_model is not None:
                 fixed.append(Row(self.Z64[s0:s0 + nc]))
-            if use_cov:
+            # <XXz_a, U Z>: U Z = W G lies in span(W), so it is also sum_{s, m} <A_a[s], W_m> G[m, s] -- the projections computed
+            # below anyway.  Taken that way when the U Z row would be the 17th fixed row (RHE_DOM with 8 bins + covariates: 16
+            # estimates): the one-read kernel takes 16 fixed rows per pass over the stored sketches.
+            tk_proj = use_cov and (self.force_tk_proj or len(fixed) == 16)
+            if use_cov and not tk_proj:
                 fixed.append(Row(self.UZ64[s0:s0 + nc]))
             # one pass over the stored XXz rows: -<b_a, fixed>, the projections -<b_a[s], W_m> and <b_a, b_b>
             bpart, bA_flat, bA_self = self._blk_products(A_blk, fixed, Wr if use_cov else [], True, nc, batch)
@@ -1280,10 +1292,10 @@ class SketchRunner:
             if self.genie_model is not None:
                 tz = acc(tz, g[:, :, col]); col += 1
             if use_cov:
-                tk = acc(tk, g[:, :, col])
                 Dr = [Row(D_tot[a, s0:s0 + nc]) for a in range(D_tot.shape[0])] + ([Row(nD[s0:s0 + nc])] if nD is not None else [])
                 tA = self._dots(self._sub_rows(A_tot, nc), Wr, 1, 1).reshape(1, ne, nc, c)      # whole-data parts: once per pass
                 PA_l.append(tA + bA_flat); PbA_l.append(-bA_flat)
+                tk = acc(tk, torch.einsum("zasm,ms->za", PA_l[-1], self.G64[:, s0:s0 + nc]) if tk_proj else g[:, :, col])
                 if self.cross:
                     # XXUz is kept as W^T XXUz = S (Q W^T Z) only (see __init__); UXXz lies in span(W), so its products with
                     # XXUz go through W^T UXXz (whole-data rows, once per pass 2)

@@ -46,6 +46,23 @@ def test_cross_columns_give_the_systems_of_the_materialised_xxuz(name, compat, s
     assert np.abs(st.T - sm.T).max() <= 1e-9 * scale.max()
 
 
+@pytest.mark.parametrize("name,compat,streaming,materialize", [("rhe_3bin_cov", "fixed", False, False), ("srhe_3bin_cov", "reference", True, True),
+                                                              ("rhe_2bin_cov_k35", "fixed", False, False), ("genie_gxe_nxe_cov", "reference", False, False),
+                                                              ("genie_gxe_cov", "fixed", True, True)])
+def test_xxz_uz_products_through_the_covariate_projections(name, compat, streaming, materialize):
+    """<XXz_a, U Z> of the normal equations (base.py:611-618) as sum_{s, m} <XXz_a[s], W_m> (Q W^T Z)[m, s] -- U Z = W (Q W^T Z)
+    lies in span(W) -- instead of a product with the U Z rows: what pass 2 does when those rows would be the 17th fixed row of
+    its one-read kernel (16 estimates: RHE_DOM with 8 bins + covariates).  Same systems, both covariate forms, every family."""
+    ra, p, _ = _runner(name, materialize, compat, streaming)
+    rb, _, _ = _runner(name, materialize, compat, streaming)
+    rb.force_tk_proj = True
+    sa = ra.run_trait(p.pheno[:, 0])
+    sb = rb.run_trait(p.pheno[:, 0])
+    scale = np.abs(sa.T).max()
+    assert np.abs(sa.T - sb.T).max() <= 1e-10 * scale
+    assert np.array_equal(sa.q, sb.q)
+
+
 def test_cross_gram_equals_projection_of_the_reference_xxuz_blocks():
     """S_a (Q W^T z_b) per block against W^T applied to the REFERENCE's own per-block XXUz arrays."""
     rc, p, z = _runner("rhe_3bin_cov", False, "fixed", False)
