@@ -1146,12 +1146,56 @@ class SketchRunner:
         b = self._dots(blk_rows, y, n_sub, batch)                  # rows evaluate to -blk
         return t + b, -b
 
+    def _multi_products(self, multi, live, y_sub, y_flat, want_self, nc, batch):
+        """``pyrhe_engine_loo_dots_multi`` beyond its 16 x 16 shapes.  More than 16 sub-strided fixed rows (GENIE with 8 bins: 16
+        estimates + Z): further calls for the rest.  More than 16 block rows (over 16 estimates: 32 bins, RHE_DOM with 12): the
+        rows go in OCTETS and every pair of octets shares one call, whose 16 x 16 self products then hold that pair's cross block
+        -- all of ``<blk_a, blk_b>`` from the one-read kernel; the calls (0, 1), (2, 3), ... also deliver the products with the
+        fixed rows.  (32 bins + covariates at N = 500k: pass 2 494 -> see DESIGN 3.4c.)"""
+        f64 = dict(dtype=torch.float64, device=self.device)
+        L, P = len(live), self.n_pad
+
+        def with_fixed(rows):
+            """sub / flat / self products of <= 16 block rows against all fixed rows"""
+            o_sub, o_flat, o_self = multi(rows, y_sub[:16], y_flat, want_self, P, nc, batch)
+            for c0 in range(16, len(y_sub), 16):
+                o_sub = torch.cat([o_sub, multi(rows, y_sub[c0:c0 + 16], [], False, P, nc, batch)[0]], dim=2)
+            return o_sub, o_flat, o_self
+
+        if L <= 16:
+            return with_fixed(live)
+        octs = [list(range(i, min(i + 8, L))) for i in range(0, L, 8)]
+        G = len(octs)
+        o_sub = torch.zeros((batch, L, len(y_sub)), **f64)
+        o_flat = torch.zeros((batch, L, nc, len(y_flat)), **f64) if y_flat else None
+        o_self = torch.zeros((batch, L, L), **f64) if want_self else None
+        first = [(i, i + 1) if i + 1 < G else (i - 1, i) for i in range(0, G, 2)]     # every octet once (the last may repeat one)
+        rest = [(i, j) for i in range(G) for j in range(i + 1, G) if (i, j) not in first] if want_self else []
+        done = set()
+        for pi, (i, j) in enumerate(first + rest):
+            rix = octs[i] + octs[j]
+            rows = [live[t] for t in rix]
+            ix = torch.as_tensor(rix, device=self.device)
+            if pi < len(first):
+                a_sub, a_flat, a_self = with_fixed(rows)
+                new = [t_ for t_, r_ in enumerate(rix) if r_ not in done]
+                sel = ix[new]
+                o_sub[:, sel] = a_sub[:, new]
+                if o_flat is not None:
+                    o_flat[:, sel] = a_flat[:, new]
+                done.update(rix)
+            else:
+                a_self = multi(rows, y_sub[:1], [], True, P, nc, batch)[2]
+            if want_self:
+                o_self[:, ix[:, None], ix[None, :]] = a_self
+        return o_sub, o_flat, o_self
+
     def _blk_products(self, rows_blk, y_sub, y_flat, want_self, nc, batch):
         """All pass-2 products of the block-only rows ``rows_blk`` (None = an exact zero row; rows evaluate to ``-blk``):
         ``b_sub [batch, n, len(y_sub)]`` against the sub-strided fixed rows, ``b_flat [batch, n, nc, len(y_flat)]`` against
         the flat fixed rows per sub-row (None without flat rows), ``b_self [batch, n, n]`` against themselves (None unless
-        asked).  ONE pass over the store through ``pyrhe_engine_loo_dots_multi`` where the shapes allow (<= 16 rows each),
-        otherwise the three ``loo_dots`` calls it stands for."""
+        asked).  Through ``pyrhe_engine_loo_dots_multi`` -- ONE pass over the store up to 16 x 16 rows, a few for more
+        (``_multi_products``) -- wherever the rows have its form, otherwise the three ``loo_dots`` calls it stands for."""
         n = len(rows_blk)
         idx = [i for i, r in enumerate(rows_blk) if r is not None]
         f64 = dict(dtype=torch.float64, device=self.device)
@@ -1161,15 +1205,11 @@ class SketchRunner:
                     torch.zeros((batch, n, n), **f64) if want_self else None)
         live = [rows_blk[i] for i in idx]
         multi = getattr(self.eng, "loo_dots_multi", None)
-        # more than 16 sub-strided fixed rows (GENIE with 8 bins: 16 estimates + Z): a second pass over the store for the rest
-        y_more = y_sub[16:] if len(y_sub) > 16 else []
-        y_sub = y_sub[:16]
-        if multi is not None and self.eng.multi_ok(live, y_sub, y_flat, self.n_pad) and \
-                (not y_more or self.eng.multi_ok(live, y_more, [], self.n_pad)):
-            o_sub, o_flat, o_self = multi(live, y_sub, y_flat, want_self, self.n_pad, nc, batch)
-            if y_more:
-                o_sub = torch.cat([o_sub, multi(live, y_more, [], False, self.n_pad, nc, batch)[0]], dim=2)
-            y_sub = y_sub + y_more
+        flat_ok = len(y_flat) <= 16
+        if multi is not None and flat_ok and self.eng.multi_ok(live[:16], y_sub[:16], y_flat, self.n_pad) and \
+                all(self.eng.multi_ok([r], y_sub[:1], [], self.n_pad) for r in live[16:]) and \
+                all(self.eng.multi_ok(live[:1], [r], [], self.n_pad) for r in y_sub[16:]):
+            o_sub, o_flat, o_self = self._multi_products(multi, live, y_sub, y_flat, want_self, nc, batch)
             if len(idx) == n:
                 return o_sub, o_flat, o_self
             ix = torch.as_tensor(idx, device=self.device)
@@ -1183,7 +1223,6 @@ class SketchRunner:
                 b_self = torch.zeros((batch, n, n), **f64)
                 b_self[:, ix[:, None], ix[None, :]] = o_self
             return b_sub, b_flat, b_self
-        y_sub = y_sub + y_more
         b_sub = self._dots(rows_blk, y_sub, nc, batch)
         b_flat = None
         if y_flat:

@@ -92,18 +92,19 @@ def test_linearity_and_block_additivity_at_bench_sample_count():
 
 
 @pytest.mark.parametrize("case", ["rhe_cov", "genie_nxe_cov", "dom_cov", "rhe_cov_q4", "rhe_recompute", "dom_cov_recompute", "genie_materialised",
-                                  "dom_cov_8bins", "genie_cov_8bins"])
+                                  "dom_cov_8bins", "genie_cov_8bins", "rhe_cov_20bins", "rhe_cov_32bins", "dom_20bins"])
 def test_pass2_device_assembly_equals_materialised_torch_path(case):
     """The normal equations assembled from pyrhe_engine_loo_dots (batched, expanded around the whole-data rows,
     covariate projector applied through projections) equal the ones from materialised leave-one-out arrays and torch
     float64 reductions -- every model family, covariates, both UXXz semantics, stored and re-sketched blocks.
     Sixteen estimates (8 bins under RHE_DOM or G + GxE): the one-read kernel takes 16 fixed rows per pass over the stored
     sketches -- with covariates <XXz, U Z> then comes from the covariate projections (RHE_DOM: exactly 16 rows left), and what
-    still exceeds 16 (GENIE: + Z and U Z) goes in a second pass."""
+    still exceeds 16 (GENIE: + Z and U Z) goes in a second pass.  More than 16 estimates (20 / 32 bins, RHE_DOM with 20): the
+    block rows go through the kernel in octets, every pair of octets sharing one call (SketchRunner._multi_products)."""
     from pyrhe_amd import engine
     from pyrhe_amd.streaming import BlockPlan, SketchRunner
     dev = torch.device("cuda", 0)
-    n, m, jn, k, nbin = 6000, 1200, 8, 10, (8 if case.endswith("8bins") else 3)
+    n, m, jn, k, nbin = 6000, 1200, 8, 10, (int(case.rsplit("_", 1)[1][:-4]) if case.endswith("bins") else 3)
     geno = engine.synth_genotypes(m, n, SEED, 11, dev)
     rng = np.random.default_rng(9)
     annot = np.zeros((m, nbin), np.int64)
@@ -122,6 +123,8 @@ def test_pass2_device_assembly_equals_materialised_torch_path(case):
         n_eng = 2                                                    # 4 k + 2 columns
     elif case in ("dom_cov", "dom_cov_8bins"):
         kw.update(dom=True)
+    elif case == "dom_20bins":
+        kw.update(dom=True, cov=None)
     elif case == "genie_cov_8bins":
         kw.update(env=env, genie_model="G+GxE")
         n_eng = 2
