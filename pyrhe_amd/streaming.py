@@ -288,6 +288,7 @@ class SketchRunner:
             self.env_pad = self._pad_cols(torch.from_numpy(self.env[None, :]))[0]            # [n_pad] f64
             self.env32 = self.env_pad.to(torch.float32)
         self.pass2_impl = "hip"       # "torch": materialised cross-check path (tests)
+        self.batch_pieces = True      # the row pieces of a block beyond the 32-bit row span go in ONE engine call where the engine allows
         self.force_tk_proj = False    # tests: <XXz, U Z> through the covariate projections even where the U Z row has room (_loo_systems)
         self.norm_digits = 3          # int8 digits of the phenotype columns in GEMM 1 (precision experiments: tools/r3_ydigits.sh)
         self.one_slot = False         # this trait group keeps ONE block slot and re-sketches in pass 2 (begin_trait decides)
@@ -620,7 +621,30 @@ class SketchRunner:
                     has_cr = self.pass_cross[p] > 0
                     ocr = self.blocks_cr[p][jl] if has_cr else None
                     ocrd = self.blocks_crd[p][jl] if (has_cr and self.dom) else None
-                    if pieces is not None:          # a block beyond the 32-bit row offsets of one call: row sub-ranges
+                    if pieces is not None and self.batch_pieces and not self.dom and self._lists_may_span_calls():
+                        # A block beyond the 32-bit row span, in ONE call: every piece is a window of n_bin lists of its own
+                        # (PYRHE_OPT_LIST_SPAN: each window spans < 2^32 bytes, the call may span more), the pieces' outputs are
+                        # added afterwards -- one GEMM 1 launch over all rows of the block instead of one per piece (N = 500k,
+                        # 100 000-SNP blocks: GEMM 1 28.4 -> 27.1 ms per pass, mid kernels 2.4 -> 2.1).  Blocks this long are what M of several millions gives at
+                        # jn = 100.
+                        P_ = len(pieces)
+                        key = ("pieces_cat", js[0], P_)
+                        if key not in self._entries_cache:
+                            offs_all = np.concatenate([[0]] + [pc[3][1:] + sum(int(q_[3][-1]) for q_ in pieces[:i_])
+                                                               for i_, pc in enumerate(pieces)]).astype(np.int64)
+                            self._entries_cache[key] = (torch.cat([pc[2] + int(pc[0]) for pc in pieces]), offs_all)
+                        ent_all, offs_all = self._entries_cache[key]
+                        tgt_sk, tgt_nm = out_sk[p][jl], out_norm[p][jl]
+                        tmp_sk = torch.empty((P_ * nb,) + tuple(tgt_sk.shape[1:]), dtype=tgt_sk.dtype, device=self.device)
+                        tmp_nm = torch.empty((P_ * nb,) + tuple(tgt_nm.shape[1:]), dtype=tgt_nm.dtype, device=self.device)
+                        tmp_cr = torch.empty((P_ * nb,) + tuple(ocr.shape[1:]), dtype=ocr.dtype, device=self.device) if has_cr else None
+                        self._sketch_call(p, rows, ent_all, offs_all, fill, tmp_sk, tmp_nm, ocr=tmp_cr)
+                        torch.sum(tmp_sk.view(P_, nb, *tgt_sk.shape[1:]), dim=0, out=tgt_sk)
+                        torch.sum(tmp_nm.view(P_, nb, *tgt_nm.shape[1:]), dim=0, out=tgt_nm)
+                        if has_cr:
+                            torch.sum(tmp_cr.view(P_, nb, *ocr.shape[1:]), dim=0, out=ocr)
+                        del tmp_sk, tmp_nm, tmp_cr
+                    elif pieces is not None:        # a block beyond the 32-bit row offsets of one call: row sub-ranges
                         for i_, (a, b, ent_p, offs_p) in enumerate(pieces):
                             self._sketch_call(p, rows[a:b], ent_p, offs_p, None if fill is None else fill[a:b].contiguous(),
                                               out_sk[p][jl], out_norm[p][jl], self.blocks_skd[p][jl] if self.dom else None,

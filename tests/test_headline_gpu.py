@@ -280,6 +280,43 @@ def test_blocks_beyond_one_call_are_split_into_row_pieces():
         assert np.allclose(o.q, out[0].q, rtol=2e-6)
 
 
+@pytest.mark.parametrize("nbin,n_cov", [(1, 0), (3, 4)])
+def test_long_blocks_row_pieces_in_one_call_equal_one_call_per_piece(nbin, n_cov):
+    """N = 500 000 with 36 000-SNP blocks (4.5 GB of rows: beyond the 32-bit row span of a call; what M of several millions
+    gives at jn = 100): the row pieces of a block as list windows of ONE engine call (one GEMM 1 launch over the block,
+    PYRHE_OPT_LIST_SPAN) against one call per piece, later pieces accumulating (`batch_pieces = False`).  Same systems."""
+    from pyrhe_amd import engine
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner, engine_capacity
+    dev = torch.device("cuda", 0)
+    n, m, jn, k = 500_000, 72_000, 2, 10
+    geno = engine.recode_rows(engine.synth_genotypes(m, n, SEED, 77, dev), "value")
+    annot = np.zeros((m, nbin), np.int64)
+    annot[np.arange(m), (np.arange(m) * 5 + 1) % nbin] = 1
+    plan = BlockPlan(annot, jn)
+    Z = np.random.default_rng(5).standard_normal((n, k)).astype(np.float32)
+    y = np.random.default_rng(6).standard_normal(n); y -= y.mean()
+    cov = None
+    if n_cov:
+        cov = np.random.default_rng(7).standard_normal((n, n_cov)); cov[:, 0] = 1.0
+    out = []
+    for batch in (True, False):
+        eng = engine.SketchEngine(n, n, max_entries=engine_capacity(plan, n), precision="i8x3", device=dev, sub_snps=engine_capacity(plan, n))
+        eng.set_coding("value")
+        runner = SketchRunner([eng], geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True, compat="fixed")
+        runner.batch_pieces = batch
+        runner.begin_trait(y, check_missing=False)
+        assert runner._pieces(0) is not None and len(runner._pieces(0)) == 2
+        runner.pass1()
+        out.append(runner.pass2())
+        eng.close()
+        del runner
+        torch.cuda.empty_cache()
+    a, b = out
+    assert np.array_equal(a.M, b.M)
+    assert np.abs(a.T - b.T).max() <= 2e-6 * np.abs(b.T).max()
+    assert np.allclose(a.q, b.q, rtol=2e-6)
+
+
 def test_projector_kernel_vs_oracle_float32_chain():
     """pyrhe_engine_apply_projector (Base._compute_UXXz, base.py:407-408) against the oracle's float32
     mat_mul chain W (Q (W^T v)) and against a float64 evaluation."""
