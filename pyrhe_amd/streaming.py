@@ -108,6 +108,8 @@ MAX_ENGINE_COLS = 30            # sketch + norm columns of one engine pass (PYRH
 MAX_ENGINE_COLS_I8 = 46         # PYRHE_MAX_COLS: an int8 engine takes cross columns beyond the 30, while its packed digit rows
 MAX_DIGIT_ROWS_I8 = 96          # (3 per sketch / norm column, `cross_digits` per cross column, 1 for the ones column) fit six tiles
 MAX_SEGMENTS = 64               # kMaxSeg of the engine: (block, bin) lists one kernel chunk can hold
+SEG_CAP = 15104                 # kG2pSegCap of the engine: entries of ONE list a kernel chunk takes (GEMM 2 keeps a segment's rows in LDS);
+                                # a longer list ends the chunk -- and with it the GEMM 1 launch -- at every 15 104 entries
 
 
 def engine_capacity(plan: "BlockPlan", n_samples: Optional[int] = None) -> int:
@@ -288,7 +290,9 @@ class SketchRunner:
             self.env_pad = self._pad_cols(torch.from_numpy(self.env[None, :]))[0]            # [n_pad] f64
             self.env32 = self.env_pad.to(torch.float32)
         self.pass2_impl = "hip"       # "torch": materialised cross-check path (tests)
-        self.batch_pieces = True      # the row pieces of a block beyond the 32-bit row span go in ONE engine call where the engine allows
+        # long blocks (lists beyond SEG_CAP entries, rows beyond the 32-bit span) go into their call as row pieces = list windows
+        # of their own where the engine allows (_windows); PYRHE_BATCH_PIECES=0: the engine's own chunking / one call per piece
+        self.batch_pieces = os.environ.get("PYRHE_BATCH_PIECES", "1") != "0"
         self.force_tk_proj = False    # tests: <XXz, U Z> through the covariate projections even where the U Z row has room (_loo_systems)
         self.norm_digits = 3          # int8 digits of the phenotype columns in GEMM 1 (precision experiments: tools/r3_ydigits.sh)
         self.one_slot = False         # this trait group keeps ONE block slot and re-sketches in pass 2 (begin_trait decides)
@@ -454,8 +458,10 @@ class SketchRunner:
         cap = int(getattr(self.eng, "sub_snps", 0)) or self.plan.max_block
         by_entries = cap // max(self.plan.max_block, 1)
         by_bytes = self._row_limit() // max(self.plan.max_block, 1)
-        if by_bytes >= 1 and by_bytes < by_entries and self._lists_may_span_calls():
-            by_bytes = by_entries          # the call addresses every list relative to its own lowest row (PYRHE_OPT_LIST_SPAN)
+        if by_bytes < by_entries and self._lists_may_span_calls() and (by_bytes >= 1 or self._window_calls_ok()):
+            # the call addresses every list relative to its own lowest row (PYRHE_OPT_LIST_SPAN); blocks beyond the row span of
+            # ONE list go in as row pieces, each a window of lists of its own (_windows)
+            by_bytes = by_entries
         by_lists = MAX_SEGMENTS // max(self.plan.n_bin, 1)
         # (Choosing the batch so that GEMM 2's launch fills whole rounds of resident workgroups -- N = 50k: 10 blocks = 490
         # workgroups in one round of 512 instead of 13 = 637 in two -- was measured: GEMM 2 1.34 -> 1.21 ms per pass, GEMM 1
@@ -504,6 +510,32 @@ class SketchRunner:
             self._span_ok = bool(ok)
         return self._span_ok
 
+    def _window_calls_ok(self) -> bool:
+        """Whether the row pieces of blocks may go into one engine call as list windows of their own (outputs added afterwards):
+        the engine addresses every window relative to its own lowest row (PYRHE_OPT_LIST_SPAN); RHE_DOM keeps one call per piece."""
+        return bool(self.batch_pieces and not self.dom and self._lists_may_span_calls())
+
+    def _windows(self, js):
+        """The blocks ``js`` (consecutive) of ONE engine call as list windows: every block whole, or in its row pieces (_pieces).
+        Returns ``(entries, offsets, window -> index in js)``; rows are relative to the first row of the batch."""
+        key = ("windows", js[0], js[-1], self._row_limit())
+        if key not in self._entries_cache:
+            first = self.plan.range(js[0])[0]
+            ents, offs, wb, pos = [], [0], [], 0
+            for bi, j in enumerate(js):
+                base = self.plan.range(j)[0] - first
+                pcs = self._pieces(j)
+                if pcs is None:
+                    ent_j, offs_j = self._entries(j)
+                    pcs = [(0, None, ent_j, np.asarray(offs_j, np.int64))]
+                for a, _, ent_p, offs_p in pcs:
+                    ents.append(ent_p + int(base + a))
+                    offs.extend((pos + np.asarray(offs_p[1:], np.int64)).tolist())
+                    pos += int(offs_p[-1])
+                    wb.append(bi)
+            self._entries_cache[key] = (torch.cat(ents).to(torch.int32), np.asarray(offs, np.int64), wb)
+        return self._entries_cache[key]
+
     def _row_limit(self) -> int:
         """Rows one engine call can address: its row byte offsets are 32-bit (rows * pitch < 2^32, rows < 2^24)."""
         if self.row_limit is not None:
@@ -518,14 +550,32 @@ class SketchRunner:
         sketch is the sum over its SNPs in any grouping (float32 additions in list order either way).  None: one call."""
         s, e = self.plan.range(j)
         lim = self._row_limit()
-        if e - s <= lim:
+        # Where the pieces of a call go in together as list WINDOWS (_window_calls_ok), no list of a piece exceeds what one kernel
+        # chunk takes of a list (SEG_CAP): a longer list would end the chunk -- one GEMM 1 launch per 15 104 entries, N = 500k with
+        # blocks of 16 667 ... 33 333 SNPs: GEMM 1 25.6 - 27.1 ms per pass against 23.1 (tools/r3_s38.sh).
+        lim_list = SEG_CAP if self._window_calls_ok() else None
+        cat, offs = self.plan.entries(j)
+        if e - s <= lim and (lim_list is None or max(int(offs[b_ + 1] - offs[b_]) for b_ in range(self.plan.n_bin)) <= lim_list):
             return None
-        key = ("pieces", j, lim)
+        key = ("pieces", j, lim, lim_list)
         if key not in self._entries_cache:
-            cat, offs = self.plan.entries(j)
             out = []
-            for a in range(0, e - s, lim):
-                b = min(a + lim, e - s)
+            bounds, a = [], 0
+            n_p = -(-(e - s) // lim)                                # pieces of about equal size, as few as the limits allow
+            if lim_list is not None:
+                n_p = max(n_p, max(-(-int(offs[b_ + 1] - offs[b_]) // lim_list) for b_ in range(self.plan.n_bin)))
+            step = min(lim, -(-(e - s) // n_p))
+            while a < e - s:
+                b = min(a + step, e - s)
+                if lim_list is not None:
+                    for bn in range(self.plan.n_bin):
+                        l = cat[offs[bn]:offs[bn + 1]]
+                        ia = int(np.searchsorted(l, a))
+                        if ia + lim_list < len(l):
+                            b = min(b, int(l[ia + lim_list]))      # the row of the first entry beyond the limit: exclusive bound
+                bounds.append((a, b))
+                a = b
+            for a, b in bounds:
                 lists = []
                 for bn in range(self.plan.n_bin):
                     l = cat[offs[bn]:offs[bn + 1]]
@@ -616,33 +666,38 @@ class SketchRunner:
                         fill = torch.cat([f if f is not None else torch.zeros(m_, dtype=torch.float32, device=self.device)
                                           for f, m_ in parts]) if len(parts) > 1 else parts[0][0]
                         fills.append(fill)
-                pieces = self._pieces(js[0]) if len(js) == 1 else None
+                # Blocks whose lists are longer than a kernel chunk takes (or whose rows pass the 32-bit span): their row pieces go
+                # into the SAME call as list windows of their own, the windows' outputs are added per block afterwards -- one
+                # GEMM 1 launch over all rows of the call instead of one per 15 104 entries (N = 500k, 20 000-SNP blocks: GEMM 1
+                # 25.9 -> 24.4 ms per pass, the mid kernels 2.0 -> 0.4).  Blocks this long are what M of several millions gives at jn = 100.
+                win = None
+                if self._window_calls_ok() and any(self._pieces(j) is not None for j in js):
+                    win = self._windows(js)
+                pieces = self._pieces(js[0]) if (len(js) == 1 and win is None) else None
                 for p in range(self.n_pass):
                     has_cr = self.pass_cross[p] > 0
                     ocr = self.blocks_cr[p][jl] if has_cr else None
                     ocrd = self.blocks_crd[p][jl] if (has_cr and self.dom) else None
-                    if pieces is not None and self.batch_pieces and not self.dom and self._lists_may_span_calls():
-                        # A block beyond the 32-bit row span, in ONE call: every piece is a window of n_bin lists of its own
-                        # (PYRHE_OPT_LIST_SPAN: each window spans < 2^32 bytes, the call may span more), the pieces' outputs are
-                        # added afterwards -- one GEMM 1 launch over all rows of the block instead of one per piece (N = 500k,
-                        # 100 000-SNP blocks: GEMM 1 28.4 -> 27.1 ms per pass, mid kernels 2.4 -> 2.1).  Blocks this long are what M of several millions gives at
-                        # jn = 100.
-                        P_ = len(pieces)
-                        key = ("pieces_cat", js[0], P_)
-                        if key not in self._entries_cache:
-                            offs_all = np.concatenate([[0]] + [pc[3][1:] + sum(int(q_[3][-1]) for q_ in pieces[:i_])
-                                                               for i_, pc in enumerate(pieces)]).astype(np.int64)
-                            self._entries_cache[key] = (torch.cat([pc[2] + int(pc[0]) for pc in pieces]), offs_all)
-                        ent_all, offs_all = self._entries_cache[key]
-                        tgt_sk, tgt_nm = out_sk[p][jl], out_norm[p][jl]
-                        tmp_sk = torch.empty((P_ * nb,) + tuple(tgt_sk.shape[1:]), dtype=tgt_sk.dtype, device=self.device)
-                        tmp_nm = torch.empty((P_ * nb,) + tuple(tgt_nm.shape[1:]), dtype=tgt_nm.dtype, device=self.device)
-                        tmp_cr = torch.empty((P_ * nb,) + tuple(ocr.shape[1:]), dtype=ocr.dtype, device=self.device) if has_cr else None
-                        self._sketch_call(p, rows, ent_all, offs_all, fill, tmp_sk, tmp_nm, ocr=tmp_cr)
-                        torch.sum(tmp_sk.view(P_, nb, *tgt_sk.shape[1:]), dim=0, out=tgt_sk)
-                        torch.sum(tmp_nm.view(P_, nb, *tgt_nm.shape[1:]), dim=0, out=tgt_nm)
-                        if has_cr:
-                            torch.sum(tmp_cr.view(P_, nb, *ocr.shape[1:]), dim=0, out=ocr)
+                    if win is not None:
+                        ent_w, offs_w, wb = win
+                        n_w = len(wb)
+                        tgt_sk, tgt_nm = out_sk[p][jl:jl + len(js)], out_norm[p][jl:jl + len(js)]
+                        tgt_cr = self.blocks_cr[p][jl:jl + len(js)] if has_cr else None
+                        tmp_sk = torch.empty((n_w * nb,) + tuple(tgt_sk.shape[2:]), dtype=tgt_sk.dtype, device=self.device)
+                        tmp_nm = torch.empty((n_w * nb,) + tuple(tgt_nm.shape[2:]), dtype=tgt_nm.dtype, device=self.device)
+                        tmp_cr = torch.empty((n_w * nb,) + tuple(tgt_cr.shape[2:]), dtype=tgt_cr.dtype, device=self.device) if has_cr else None
+                        self._sketch_call(p, rows, ent_w, offs_w, fill, tmp_sk, tmp_nm, ocr=tmp_cr)
+                        if hasattr(self.engs[p], "join"):
+                            self.engs[p].join()       # (a no-op unless the engine runs its private two-stream pipeline)
+                        w0 = 0
+                        for bi in range(len(js)):
+                            w1 = w0
+                            while w1 < n_w and wb[w1] == bi:
+                                w1 += 1
+                            for tmp, tgt in ((tmp_sk, tgt_sk), (tmp_nm, tgt_nm), (tmp_cr, tgt_cr)):
+                                if tmp is not None:
+                                    torch.sum(tmp[w0 * nb:w1 * nb].view(w1 - w0, nb, *tgt.shape[2:]), dim=0, out=tgt[bi])
+                            w0 = w1
                         del tmp_sk, tmp_nm, tmp_cr
                     elif pieces is not None:        # a block beyond the 32-bit row offsets of one call: row sub-ranges
                         for i_, (a, b, ent_p, offs_p) in enumerate(pieces):

@@ -280,15 +280,17 @@ def test_blocks_beyond_one_call_are_split_into_row_pieces():
         assert np.allclose(o.q, out[0].q, rtol=2e-6)
 
 
-@pytest.mark.parametrize("nbin,n_cov", [(1, 0), (3, 4)])
-def test_long_blocks_row_pieces_in_one_call_equal_one_call_per_piece(nbin, n_cov):
-    """N = 500 000 with 36 000-SNP blocks (4.5 GB of rows: beyond the 32-bit row span of a call; what M of several millions
-    gives at jn = 100): the row pieces of a block as list windows of ONE engine call (one GEMM 1 launch over the block,
-    PYRHE_OPT_LIST_SPAN) against one call per piece, later pieces accumulating (`batch_pieces = False`).  Same systems."""
+@pytest.mark.parametrize("nbin,n_cov,m,jn,n_pieces", [(1, 0, 72_000, 2, 3), (3, 4, 72_000, 2, 2), (1, 0, 60_000, 3, 2)])
+def test_long_blocks_row_pieces_in_one_call_equal_one_call_per_piece(nbin, n_cov, m, jn, n_pieces):
+    """N = 500 000 with 36 000-SNP blocks (4.5 GB of rows: beyond the 32-bit row span of a call) and with 20 000-SNP blocks (one
+    list longer than the 15 104 entries a kernel chunk takes of a list) -- what M of several millions gives at jn = 100: the
+    row pieces of the blocks of a call as list windows of ONE engine call (one GEMM 1 launch over all its rows,
+    PYRHE_OPT_LIST_SPAN; three 20 000-SNP blocks = six windows) against the engine's own handling (`batch_pieces = False`: one
+    call per piece beyond the row span, later pieces accumulating; long lists cut into chunks).  Same systems."""
     from pyrhe_amd import engine
     from pyrhe_amd.streaming import BlockPlan, SketchRunner, engine_capacity
     dev = torch.device("cuda", 0)
-    n, m, jn, k = 500_000, 72_000, 2, 10
+    n, k = 500_000, 10
     geno = engine.recode_rows(engine.synth_genotypes(m, n, SEED, 77, dev), "value")
     annot = np.zeros((m, nbin), np.int64)
     annot[np.arange(m), (np.arange(m) * 5 + 1) % nbin] = 1
@@ -305,7 +307,8 @@ def test_long_blocks_row_pieces_in_one_call_equal_one_call_per_piece(nbin, n_cov
         runner = SketchRunner([eng], geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True, compat="fixed")
         runner.batch_pieces = batch
         runner.begin_trait(y, check_missing=False)
-        assert runner._pieces(0) is not None and len(runner._pieces(0)) == 2
+        pcs = runner._pieces(0)
+        assert (len(pcs) == n_pieces) if batch else ((pcs is None) == (m // jn <= 34_308))
         runner.pass1()
         out.append(runner.pass2())
         eng.close()
