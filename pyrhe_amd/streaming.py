@@ -512,8 +512,8 @@ class SketchRunner:
 
     def _window_calls_ok(self) -> bool:
         """Whether the row pieces of blocks may go into one engine call as list windows of their own (outputs added afterwards):
-        the engine addresses every window relative to its own lowest row (PYRHE_OPT_LIST_SPAN); RHE_DOM keeps one call per piece."""
-        return bool(self.batch_pieces and not self.dom and self._lists_may_span_calls())
+        the engine addresses every window relative to its own lowest row (PYRHE_OPT_LIST_SPAN)."""
+        return bool(self.batch_pieces and self._lists_may_span_calls())
 
     def _windows(self, js):
         """The blocks ``js`` (consecutive) of ONE engine call as list windows: every block whole, or in its row pieces (_pieces).
@@ -681,12 +681,14 @@ class SketchRunner:
                     if win is not None:
                         ent_w, offs_w, wb = win
                         n_w = len(wb)
-                        tgt_sk, tgt_nm = out_sk[p][jl:jl + len(js)], out_norm[p][jl:jl + len(js)]
-                        tgt_cr = self.blocks_cr[p][jl:jl + len(js)] if has_cr else None
-                        tmp_sk = torch.empty((n_w * nb,) + tuple(tgt_sk.shape[2:]), dtype=tgt_sk.dtype, device=self.device)
-                        tmp_nm = torch.empty((n_w * nb,) + tuple(tgt_nm.shape[2:]), dtype=tgt_nm.dtype, device=self.device)
-                        tmp_cr = torch.empty((n_w * nb,) + tuple(tgt_cr.shape[2:]), dtype=tgt_cr.dtype, device=self.device) if has_cr else None
-                        self._sketch_call(p, rows, ent_w, offs_w, fill, tmp_sk, tmp_nm, ocr=tmp_cr)
+                        sl = slice(jl, jl + len(js))
+                        # targets: additive sketch / norm / cross Gram, then RHE_DOM's dominance counterparts (None: not in this run)
+                        tgts = [out_sk[p][sl], out_norm[p][sl], self.blocks_cr[p][sl] if has_cr else None,
+                                self.blocks_skd[p][sl] if self.dom else None, self.blocks_nmd[p][sl] if self.dom else None,
+                                self.blocks_crd[p][sl] if (has_cr and self.dom) else None]
+                        tmps = [None if t is None else torch.empty((n_w * nb,) + tuple(t.shape[2:]), dtype=t.dtype, device=self.device)
+                                for t in tgts]
+                        self._sketch_call(p, rows, ent_w, offs_w, fill, tmps[0], tmps[1], tmps[3], tmps[4], ocr=tmps[2], ocrd=tmps[5])
                         if hasattr(self.engs[p], "join"):
                             self.engs[p].join()       # (a no-op unless the engine runs its private two-stream pipeline)
                         w0 = 0
@@ -694,11 +696,11 @@ class SketchRunner:
                             w1 = w0
                             while w1 < n_w and wb[w1] == bi:
                                 w1 += 1
-                            for tmp, tgt in ((tmp_sk, tgt_sk), (tmp_nm, tgt_nm), (tmp_cr, tgt_cr)):
+                            for tmp, tgt in zip(tmps, tgts):
                                 if tmp is not None:
                                     torch.sum(tmp[w0 * nb:w1 * nb].view(w1 - w0, nb, *tgt.shape[2:]), dim=0, out=tgt[bi])
                             w0 = w1
-                        del tmp_sk, tmp_nm, tmp_cr
+                        del tmps
                     elif pieces is not None:        # a block beyond the 32-bit row offsets of one call: row sub-ranges
                         for i_, (a, b, ent_p, offs_p) in enumerate(pieces):
                             self._sketch_call(p, rows[a:b], ent_p, offs_p, None if fill is None else fill[a:b].contiguous(),

@@ -280,8 +280,9 @@ def test_blocks_beyond_one_call_are_split_into_row_pieces():
         assert np.allclose(o.q, out[0].q, rtol=2e-6)
 
 
-@pytest.mark.parametrize("nbin,n_cov,m,jn,n_pieces", [(1, 0, 72_000, 2, 3), (3, 4, 72_000, 2, 2), (1, 0, 60_000, 3, 2)])
-def test_long_blocks_row_pieces_in_one_call_equal_one_call_per_piece(nbin, n_cov, m, jn, n_pieces):
+@pytest.mark.parametrize("nbin,n_cov,m,jn,n_pieces,dom", [(1, 0, 72_000, 2, 3, False), (3, 4, 72_000, 2, 2, False), (1, 0, 60_000, 3, 2, False),
+                                                            (1, 3, 60_000, 3, 2, True)])
+def test_long_blocks_row_pieces_in_one_call_equal_one_call_per_piece(nbin, n_cov, m, jn, n_pieces, dom):
     """N = 500 000 with 36 000-SNP blocks (4.5 GB of rows: beyond the 32-bit row span of a call) and with 20 000-SNP blocks (one
     list longer than the 15 104 entries a kernel chunk takes of a list) -- what M of several millions gives at jn = 100: the
     row pieces of the blocks of a call as list windows of ONE engine call (one GEMM 1 launch over all its rows,
@@ -304,7 +305,7 @@ def test_long_blocks_row_pieces_in_one_call_equal_one_call_per_piece(nbin, n_cov
     for batch in (True, False):
         eng = engine.SketchEngine(n, n, max_entries=engine_capacity(plan, n), precision="i8x3", device=dev, sub_snps=engine_capacity(plan, n))
         eng.set_coding("value")
-        runner = SketchRunner([eng], geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True, compat="fixed")
+        runner = SketchRunner([eng], geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True, compat="fixed", dom=dom)
         runner.batch_pieces = batch
         runner.begin_trait(y, check_missing=False)
         pcs = runner._pieces(0)
