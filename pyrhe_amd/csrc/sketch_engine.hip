@@ -861,9 +861,14 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             }
         const int64_t total = offsets_host[nbin];
         const int64_t seg_cap = std::min<int64_t>(e->sub_snps, kG2pSegCap);   // GEMM 2 keeps a segment's row list in LDS
+        // Plan first: the chunks of the call -- what ONE segment table (kMaxSeg lists) and one pass of the mid kernels / GEMM 2 take.
+        struct Chunk { SegTab tab; int64_t chunk0; int n, kb; };
+        std::vector<Chunk> chunks;
         int b = 0;
         for (int64_t pos = 0; pos < total;) {
-            SegTab tab = {};
+            chunks.emplace_back();
+            SegTab& tab = chunks.back().tab;
+            tab = SegTab{};
             const int64_t chunk0 = pos;
             int n = 0, kb = 0;
             while (pos < total && n < e->sub_snps && tab.nseg < kMaxSeg) {
@@ -885,22 +890,48 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             }
             tab.start[tab.nseg] = n;
             tab.kb0[tab.nseg] = kb;
+            chunks.back().chunk0 = chunk0;
+            chunks.back().n = n;
+            chunks.back().kb = kb;
+        }
+        // The FIRST contraction does not need the segment table: consecutive chunks whose entries fit the P buffer (sub_snps) share
+        // ONE GEMM 1 launch (a "super-chunk"), the mid kernels and GEMM 2 then go chunk by chunk over their slice of P.  A call of
+        // many short lists (8 bins x 8 blocks fill a table at 80 000 rows of N = 500k; 32 bins at 20 000) thereby keeps full-size
+        // GEMM 1 launches.  (The private two-stream pipeline keeps one launch per chunk: its chunks alternate work sets.)
+        size_t super_end = 0;
+        int64_t super0 = 0;
+        int set = 0;
+        for (size_t ci = 0; ci < chunks.size(); ++ci) {
+            const SegTab& tab = chunks[ci].tab;
+            const int64_t chunk0 = chunks[ci].chunk0;
+            const int n = chunks[ci].n, kb = chunks[ci].kb;
             const int32_t* rows = entries + chunk0;
-            const int set = (int)(e->sub_counter & 1);
-            e->use_set(set);
-            if (piped && e->sub_counter >= 2) HIPCHK(hipStreamWaitEvent(e->sA, e->evB[set], 0));
-            e->sub_counter++;
-            { const int rcz = zero_ws(n); if (rcz) return rcz; }
-            if (dom) {      // both genotype views in one launch (one read): P2 and the per-segment maxima of the 2 [g == 2] view
-                HIPCHK(hipMemsetAsync(e->dom_ws, 0, std::min(e->dom_wmax_off, (size_t)n * ncol_p * sizeof(float)), stream));
-                HIPCHK(hipMemsetAsync(e->dom_ws + e->dom_wmax_off, 0, e->dom_zero_bytes - e->dom_wmax_off, stream));
-                run_gemm1(2, rows, n, e->P, e->P2);
-            } else {
-                run_gemm1(0, rows, n, e->P);
+            if (ci == super_end) {
+                int64_t n_super = n;
+                super_end = ci + 1;
+                if (!piped)
+                    while (super_end < chunks.size() && n_super + chunks[super_end].n <= e->sub_snps) n_super += chunks[super_end++].n;
+                super0 = chunk0;
+                set = (int)(e->sub_counter & 1);
+                e->use_set(set);
+                if (piped && e->sub_counter >= 2) HIPCHK(hipStreamWaitEvent(e->sA, e->evB[set], 0));
+                e->sub_counter++;
+                HIPCHK(hipMemsetAsync(e->ws, 0, std::min(e->zero_tail, (size_t)n_super * ncol_p * sizeof(float)), stream));      // P of the super-chunk
+                if (dom) {      // both genotype views in one launch (one read)
+                    HIPCHK(hipMemsetAsync(e->dom_ws, 0, std::min(e->dom_wmax_off, (size_t)n_super * ncol_p * sizeof(float)), stream));
+                    run_gemm1(2, rows, (int)n_super, e->P, e->P2);
+                } else {
+                    run_gemm1(0, rows, (int)n_super, e->P);
+                }
             }
+            // this chunk's slice of P (P2), its per-segment maxima / corrections
+            float* const Pc = e->P + (chunk0 - super0) * ncol_p;
+            float* const P2c = dom ? e->P2 + (chunk0 - super0) * ncol_p : nullptr;
+            HIPCHK(hipMemsetAsync(e->ws + e->zero_tail, 0, e->zero_bytes - e->zero_tail, stream));
+            if (dom) HIPCHK(hipMemsetAsync(e->dom_ws + e->dom_wmax_off, 0, e->dom_zero_bytes - e->dom_wmax_off, stream));
             {
                 ProfScope ps(e, stream, 1);
-                mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(e->P, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
+                mid1_kernel<<<(n + 63) / 64, 256, 0, stream>>>(Pc, pscale, e->i8 ? 1 : 0, n, ncol_p, e->n_sketch, e->n_norm, e->rscale, e->csum,
                                                                  (float)e->n_keep, e->mu, e->Wtmp, e->wmax, e->vsq,
                                                                  out_colsum ? out_colsum + chunk0 : nullptr, e->n_cross, e->vcross, e->nd2, e->nd3, tab);
                 if (e->n_cross)
@@ -927,7 +958,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             if (dom_fuse) {
                 {
                     ProfScope ps(e, stream, 1);
-                    mid_dom1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->P2, pscale, 1, n, ncol_p, e->n_sketch, e->n_norm, e->rscale,
+                    mid_dom1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(Pc, P2c, pscale, 1, n, ncol_p, e->n_sketch, e->n_norm, e->rscale,
                                                                          e->csum, (float)e->n_keep, e->cmu, e->W1d, e->Wtmp2, e->wmax1d, e->wmax2,
                                                                          e->vsq2, e->n_cross, e->vcross2, e->nd2, e->nd3, tab);
                     if (e->n_cross)
@@ -957,7 +988,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
                 HIPCHK(hipMemsetAsync(e->ws + e->zero_tail, 0, e->zero_bytes - e->zero_tail, stream));      // wmax | corr of every segment
                 {
                     ProfScope ps(e, stream, 1);
-                    mid_dom1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(e->P, e->P2, pscale, 1, n, ncol_p, e->n_sketch, e->n_norm, e->rscale,
+                    mid_dom1_kernel<<<(n + 255) / 256, 256, 0, stream>>>(Pc, P2c, pscale, 1, n, ncol_p, e->n_sketch, e->n_norm, e->rscale,
                                                                          e->csum, (float)e->n_keep, e->cmu, e->Wtmp, e->Wtmp2, e->wmax, e->wmax2,
                                                                          e->vsq2, e->n_cross, e->vcross2, e->nd2, e->nd3, tab);
                     if (e->n_cross)

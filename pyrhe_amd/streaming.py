@@ -462,6 +462,9 @@ class SketchRunner:
             # the call addresses every list relative to its own lowest row (PYRHE_OPT_LIST_SPAN); blocks beyond the row span of
             # ONE list go in as row pieces, each a window of lists of its own (_windows)
             by_bytes = by_entries
+        # One segment table per call: the engine takes more lists (further chunks of the call share its GEMM 1 launch), but calls of
+        # two or more tables measured SLOWER through the runner (tools/r3_s44.sh: 8 bins + covariates 58.3 -> 59.5 ms per pass, 32 bins
+        # 89.0 -> 92.9, N = 50k with 8 bins 5.5 -> 8.2: GEMM 1 gains, GEMM 2 and the per-call work lose more)
         by_lists = MAX_SEGMENTS // max(self.plan.n_bin, 1)
         # (Choosing the batch so that GEMM 2's launch fills whole rounds of resident workgroups -- N = 50k: 10 blocks = 490
         # workgroups in one round of 512 instead of 13 = 637 in two -- was measured: GEMM 2 1.34 -> 1.21 ms per pass, GEMM 1

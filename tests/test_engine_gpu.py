@@ -629,6 +629,42 @@ def test_gemm1_launch_shape_options_do_not_change_a_bit(dev):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("k,dom", [(10, False), (20, False), (10, True)])
+def test_many_short_lists_share_one_gemm1_launch(dev, k, dom):
+    """A call of more lists than one segment table holds (kMaxSeg = 64): the chunks -- one table each -- share ONE GEMM 1 launch
+    over all their rows (they fit the P buffer), the mid kernels and GEMM 2 go chunk by chunk over their slice of P.  150 lists
+    (incl. one longer than a segment may be: cut, its pieces in different chunks) against one call per list; additive and
+    dominance outputs."""
+    from pyrhe_amd import engine
+    n, m = 200_000 if dom else 30_000, 9_000
+    rng = np.random.default_rng(31)
+    packed = engine.recode_rows(engine.synth_genotypes(m, n, 3, 0, dev), "value")
+    sizes = [int(x) for x in rng.integers(1, 60, 149)] + [2500]
+    lists = [np.sort(rng.choice(m, sz, replace=False)).astype(np.int32) for sz in sizes]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+    entries = torch.from_numpy(np.concatenate(lists)).to(dev)
+    eng = engine.SketchEngine(n, n, max_entries=m, precision="i8x3", device=dev)
+    eng.set_coding("value")
+    keep = eng.keep_vector([])
+    g = torch.Generator().manual_seed(9)
+    Z = torch.zeros((k, eng.n_pad), device=dev)
+    Z[:, :n] = torch.randn((k, n), generator=g).to(dev)
+    y = torch.zeros((1, eng.n_pad), device=dev)
+    y[:, :n] = torch.randn((1, n), generator=g).to(dev)
+    eng.set_rhs(Z, y, keep)
+    call = (lambda e_, o_: eng.sketch_block_dom(packed, e_, o_)) if dom else (lambda e_, o_: eng.sketch_block(packed, e_, o_)[:2])
+    outs = [t.clone() for t in call(entries, offs)]
+    torch.cuda.synchronize()
+    assert eng.last_path()["segmented"]
+    for b in (0, 1, 63, 64, 65, 100, 148, 149):
+        e1 = torch.from_numpy(lists[b]).to(dev)
+        ones = [t.clone() for t in call(e1, [0, len(lists[b])])]
+        torch.cuda.synchronize()
+        for a, r in zip(outs, ones):
+            assert (a[b] - r[0]).abs().max().item() <= 2e-6 * max(r.abs().max().item(), 1e-30), b
+    eng.close()
+
+
 def test_stream_read_measures_a_bandwidth_and_rejects_bad_buffers(dev):
     """pyrhe_stream_read, bench.py's measuring stick (the box's measured stream bandwidth beside the nominal peak)."""
     from pyrhe_amd import engine
