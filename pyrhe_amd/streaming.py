@@ -557,11 +557,14 @@ class SketchRunner:
         # chunk takes of a list (SEG_CAP): a longer list would end the chunk -- one GEMM 1 launch per 15 104 entries, N = 500k with
         # blocks of 16 667 ... 33 333 SNPs: GEMM 1 25.6 - 27.1 ms per pass against 23.1 (tools/r3_s38.sh).
         lim_list = SEG_CAP if self._window_calls_ok() else None
-        cat, offs = self.plan.entries(j)
-        if e - s <= lim and (lim_list is None or max(int(offs[b_ + 1] - offs[b_]) for b_ in range(self.plan.n_bin)) <= lim_list):
-            return None
+        if e - s <= lim and (lim_list is None or e - s <= lim_list):
+            return None                                             # (the common case, asked for every block of every call: no work here)
         key = ("pieces", j, lim, lim_list)
         if key not in self._entries_cache:
+            cat, offs = self.plan.entries(j)
+            if e - s <= lim and max(int(offs[b_ + 1] - offs[b_]) for b_ in range(self.plan.n_bin)) <= lim_list:
+                self._entries_cache[key] = None                     # more rows than a list may have, but no single list is that long
+                return None
             out = []
             bounds, a = [], 0
             n_p = -(-(e - s) // lim)                                # pieces of about equal size, as few as the limits allow
