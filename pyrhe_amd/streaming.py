@@ -462,10 +462,14 @@ class SketchRunner:
             # the call addresses every list relative to its own lowest row (PYRHE_OPT_LIST_SPAN); blocks beyond the row span of
             # ONE list go in as row pieces, each a window of lists of its own (_windows)
             by_bytes = by_entries
-        # One segment table per call: the engine takes more lists (further chunks of the call share its GEMM 1 launch), but calls of
-        # two or more tables measured SLOWER through the runner (tools/r3_s44.sh: 8 bins + covariates 58.3 -> 59.5 ms per pass, 32 bins
-        # 89.0 -> 92.9, N = 50k with 8 bins 5.5 -> 8.2: GEMM 1 gains, GEMM 2 and the per-call work lose more)
-        by_lists = MAX_SEGMENTS // max(self.plan.n_bin, 1)
+        # Lists per call.  The engine takes more lists than ONE segment table holds (further chunks of the call share its GEMM 1
+        # launch).  Cohorts below 196 608 samples gain from that -- GEMM 1 gets rows enough for the 128-row kernel and long launches:
+        # N = 50k with 8 bins 5.62 -> 4.86 ms per pass, with 4 bins 4.07 -> 3.62, N = 100k with 8 bins 7.88 -> 7.35 -- and take WHOLE
+        # tables (a last table of fewer segments is a short GEMM 2 launch); at N = 500k GEMM 1 gains less than GEMM 2 loses (8 bins +
+        # covariates 56.9 -> 57.6 ms, 32 bins 87.7 -> 88.2, 1000-SNP blocks 57.5 -> 57.6; tools/r3_s47.sh): one table per call there.
+        by_lists = max(1, MAX_SEGMENTS // max(self.plan.n_bin, 1))
+        if self.n_pad < 192 * 1024 and os.environ.get("PYRHE_ONE_TABLE") != "1":
+            by_lists *= max(1, min(by_entries, max(by_bytes, 1)) // by_lists)
         # (Choosing the batch so that GEMM 2's launch fills whole rounds of resident workgroups -- N = 50k: 10 blocks = 490
         # workgroups in one round of 512 instead of 13 = 637 in two -- was measured: GEMM 2 1.34 -> 1.21 ms per pass, GEMM 1
         # 1.66 -> 1.77 ms with two more launches: no gain; the largest batch stays.)
