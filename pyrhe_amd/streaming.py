@@ -468,7 +468,7 @@ class SketchRunner:
         # tables (a last table of fewer segments is a short GEMM 2 launch); at N = 500k GEMM 1 gains less than GEMM 2 loses (8 bins +
         # covariates 56.9 -> 57.6 ms, 32 bins 87.7 -> 88.2, 1000-SNP blocks 57.5 -> 57.6; tools/r3_s47.sh): one table per call there.
         by_lists = max(1, MAX_SEGMENTS // max(self.plan.n_bin, 1))
-        if self.n_pad < 192 * 1024 and os.environ.get("PYRHE_ONE_TABLE") != "1":
+        if (self.n_pad < 192 * 1024 or os.environ.get("PYRHE_WHOLE_TABLES") == "1") and os.environ.get("PYRHE_ONE_TABLE") != "1":
             by_lists *= max(1, min(by_entries, max(by_bytes, 1)) // by_lists)
         # (Choosing the batch so that GEMM 2's launch fills whole rounds of resident workgroups -- N = 50k: 10 blocks = 490
         # workgroups in one round of 512 instead of 13 = 637 in two -- was measured: GEMM 2 1.34 -> 1.21 ms per pass, GEMM 1
