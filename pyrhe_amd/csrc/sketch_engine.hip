@@ -165,6 +165,7 @@ struct pyrhe_engine {
 #endif
 };
 
+static constexpr int kMaxTilesI8 = 6; // int8 GEMM 1: 16-row tiles of packed (digit, column) rows (gemm1_i8_kernel<6>, P's 96 slots per entry)
 static constexpr int kMaxTiles = 2;  // 32 logical columns: fp16 operand tiles, sketch columns of GEMM 2 (all precisions)
 static constexpr int kColCap = 48;   // per-column arrays (scale, sum, maximum): PYRHE_MAX_COLS + the ones column, rounded up
 static_assert(PYRHE_MAX_COLS + 1 <= kColCap, "column arrays hold every user column and the ones column");
@@ -236,6 +237,10 @@ extern "C" int pyrhe_engine_create(int device, int64_t n_keep, int64_t pitch, in
     e->max_entries = max_entries;
     const int ncolmax = 16 * kMaxTiles;
     e->rfrag_bytes = (size_t)e->n_pad * ncolmax * e->parts * sizeof(_Float16);
+    // int8 engines stage the packed digit image here: 16 bytes per sample and tile, up to kMaxTilesI8 tiles (set_rhs), plus the
+    // compact copy of a nearly empty last tile (2 bytes per sample).  PYRHE_PREC_I8X3_F16 has parts = 1: the fp16 size alone
+    // (64 bytes per sample) would not hold five or six tiles.
+    if (e->i8) e->rfrag_bytes = std::max(e->rfrag_bytes, (size_t)e->n_pad * (16 * kMaxTilesI8 + 2));
     HIPCHK_CREATE(hipMalloc(&e->rfrag, e->rfrag_bytes));
     HIPCHK_CREATE(hipMalloc(&e->rscale, kColCap * sizeof(float)));
     HIPCHK_CREATE(hipMalloc(&e->csum, kColCap * sizeof(double)));
@@ -361,7 +366,10 @@ extern "C" int pyrhe_engine_set_rhs(pyrhe_engine_t* e, const float* R, const int
     // Checked before anything of the engine's state changes: a refused call leaves the installed columns as they were.
     const int nslots = n_cols + 1 + nd2 + nd3;
     if (!e->i8 && (n_cols + 1 + 15) / 16 > kMaxTiles) return fail(PYRHE_EINVAL, "too many columns");
-    if (e->i8 && (nslots + 15) / 16 > 6) return fail(PYRHE_EINVAL, "%d packed digit rows exceed the six tiles of the int8 GEMM 1 (fewer columns or digits)", nslots);
+    if (e->i8 && (nslots + 15) / 16 > kMaxTilesI8) return fail(PYRHE_EINVAL, "%d packed digit rows exceed the six tiles of the int8 GEMM 1 (fewer columns or digits)", nslots);
+    if (e->i8 && (size_t)e->n_pad * 16 * ((nslots + 15) / 16) > e->rfrag_bytes)
+        return fail(PYRHE_EINVAL, "the operand image of %d tiles (%zu bytes) does not fit the engine's buffer (%zu bytes)", (nslots + 15) / 16,
+                    (size_t)e->n_pad * 16 * ((nslots + 15) / 16), e->rfrag_bytes);
     if (ns > 16 * kMaxTiles) return fail(PYRHE_EINVAL, "%d sketch columns exceed the %d of the second contraction", ns, 16 * kMaxTiles);
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(e->device));
@@ -584,7 +592,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
         // Every workgroup pays a fixed price -- the prologue and its 128 (64) rows x 16 NT slots of integer atomics per wave --
         // that a short loop does not amortise: where the row groups alone already fill the chip, no sample range gets fewer than 32
         // steps (N = 50k, 26 blocks per call: three splits of 32 steps instead of six of 16: GEMM 1 1.44 -> 1.35 ms per pass,
-        // tools/r3_c2_knobs.sh; N = 500k has 70 steps per split either way)
+        // tools/ab.sh [c2_knobs]; N = 500k has 70 steps per split either way)
         int smax = n_steps / 4 > 0 ? n_steps / 4 : 1;
         if (e->i8 && e->n_cu > 0 && n_steps / 32 >= 1 && (int64_t)gx * (n_steps / 32) >= (int64_t)e->n_cu * 2) smax = std::min(smax, n_steps / 32);
         splits = std::max(1, std::min(splits, smax));
@@ -611,7 +619,7 @@ static int sketch_impl(pyrhe_engine_t* e, const uint8_t* packed, int64_t n_rows,
             }
             // Short rows (<= 128 steps: cohorts up to 65 536 samples) whose row groups alone fill ONE round of the resident slots --
             // a full call of such a cohort: 262 144 entries = 512 groups of 512 rows -- take no sample split at all: a third of the
-            // prologues, plain stores instead of atomics (N = 50k: GEMM 1 1.29-1.36 -> 1.25 ms per pass, tools/r3_s28.sh)
+            // prologues, plain stores instead of atomics (N = 50k: GEMM 1 1.29-1.36 -> 1.25 ms per pass, tools/ab.sh [s28])
             if (wide && n_steps <= 128 && gx <= slots && (int64_t)gx * 100 >= (int64_t)slots * 85) {
                 splits = 1;
                 cps = round_cps(n_steps);
@@ -1439,14 +1447,18 @@ extern "C" int pyrhe_engine_loo_dots_multi(pyrhe_engine_t* e, const pyrhe_row_t*
             longest = std::max(longest, len);
         }
         if (e->dots_y32_bytes < (size_t)total * sizeof(float)) {
+            // sized ONCE for every row count this entry point takes at these (n_sub, period) -- 16 sub-strided + 16 flat rows --,
+            // so the later calls of a pass 2 (other row counts, same shapes) never free a buffer that is in use: the
+            // synchronising path below is left to a caller that comes back with longer rows
+            const size_t cap = std::max((size_t)total, (size_t)16 * ((size_t)n_sub + 1) * (size_t)period) * sizeof(float);
             if (e->dots_y32) {
                 HIPCHK(hipDeviceSynchronize());
                 HIPCHK(hipFree(e->dots_y32));
                 e->dots_y32 = nullptr;
                 e->dots_y32_bytes = 0;
             }
-            HIPCHK(hipMalloc(&e->dots_y32, (size_t)total * sizeof(float)));
-            e->dots_y32_bytes = (size_t)total * sizeof(float);
+            HIPCHK(hipMalloc(&e->dots_y32, cap));
+            e->dots_y32_bytes = cap;
         }
         fixed_rows_f32_kernel<<<dim3((unsigned)std::min<int64_t>(1024, (longest / 4 + 255) / 256), (unsigned)(ny_sub + ny_flat)), 256, 0, stream>>>(src, e->dots_y32);
         for (int c = 0; c < ny_sub; ++c) Ys.p[c] = reinterpret_cast<const double*>(e->dots_y32 + src.off[c]);
@@ -1458,7 +1470,7 @@ extern "C" int pyrhe_engine_loo_dots_multi(pyrhe_engine_t* e, const pyrhe_row_t*
     dim3 grid((unsigned)((ncgs + 7) / 8 * 8 * rgs));
     // float32 matrix instruction with 128-element float32 partial sums (PYRHE_OPT_DOTS_F32): automatic from 65 536 samples on,
     // where a row holds >= 512 such partial sums and the float64 sum over them averages their rounding (measured at N = 500k:
-    // sigma^2 unchanged to 16 digits, jackknife SEs 5e-9; tools/r3_dots_f32.sh); small cohorts, which gain nothing, stay float64
+    // sigma^2 unchanged to 16 digits, jackknife SEs 5e-9; tools/ab.sh [dots_f32]); small cohorts, which gain nothing, stay float64
 #define LMK(F_, S_, X_, T_) blk_multi_dots_kernel<F_, S_, X_, T_><<<grid, 256, 0, stream>>>(tab, nx, nxp, n_batch, Ys, ny_sub, Yf, ny_flat, period, chunk, (int)n_chunks, n_sub, rgs, ps, pf, pg)
 #define LM(F_, S_) do { if (dots_f32) { if (tpw == 1) LMK(F_, S_, true, 1); else if (tpw == 2) LMK(F_, S_, true, 2); else LMK(F_, S_, true, 4); } \
                         else { if (tpw == 1) LMK(F_, S_, false, 1); else if (tpw == 2) LMK(F_, S_, false, 2); else LMK(F_, S_, false, 4); } } while (0)

@@ -309,17 +309,18 @@ class SketchEngine:
                 cross_cols: Optional[torch.Tensor] = None, cross_digits: int = 3, norm_digits: int = 3):
         """sketch_cols ``[n_sketch, n_pad]`` / norm_cols ``[n_norm, n_pad]`` / cross_cols ``[n_cross, n_pad]`` float32 on the
         device, zero at dropped and padding samples.  ``cross_digits`` (1..3): int8 digits the cross columns are fed with
-        (``PYRHE_COL_DIGITS``)."""
+        (``PYRHE_COL_DIGITS``) -- one count for all of them, or one per cross column (not growing with the column index)."""
         parts = [t for t in (sketch_cols, norm_cols, cross_cols) if t is not None and t.shape[0] > 0]
         R = torch.cat(parts, dim=0).to(torch.float32).contiguous()
         assert R.shape[1] == self.n_pad and R.device == self.device
         ns = 0 if sketch_cols is None else sketch_cols.shape[0]
         nn = 0 if norm_cols is None else norm_cols.shape[0]
         nx = 0 if cross_cols is None else cross_cols.shape[0]
-        assert 1 <= int(cross_digits) <= 3 and 1 <= int(norm_digits) <= 3
-        cross_digits = min(int(cross_digits), int(norm_digits))         # digit counts do not grow with the column index
+        per_col = [int(d) for d in cross_digits] if isinstance(cross_digits, (list, tuple, np.ndarray)) else [int(cross_digits)] * nx
+        assert len(per_col) == nx and all(1 <= d <= 3 for d in per_col) and 1 <= int(norm_digits) <= 3
+        per_col = [min(d, int(norm_digits)) for d in per_col]           # digit counts do not grow with the column index
         roles = (C.c_int32 * (ns + nn + nx))(*([COL_SKETCH] * ns + [COL_NORM | (int(norm_digits) << 8)] * nn +
-                                               [COL_CROSS | (int(cross_digits) << 8)] * nx))
+                                               [COL_CROSS | (d << 8) for d in per_col]))
         keep = keep.to(torch.float32).contiguous()
         with torch.cuda.device(self.device):
             _check(self.lib.pyrhe_engine_set_rhs(self._h, _ptr(R), roles, ns + nn + nx, _ptr(keep), _stream_ptr(self.device)),

@@ -124,7 +124,33 @@ def engine_capacity(plan: "BlockPlan", n_samples: Optional[int] = None) -> int:
     return max(int(plan.max_block), int(os.environ.get("PYRHE_CAPACITY", str(default))))
 
 
-def plan_passes(k: int, n_groups: int, n_norm: int, cross=(), cross_digits: int = 3, wide: bool = False):
+def column_digits(cols: np.ndarray, base: int) -> np.ndarray:
+    """int8 digits for each cross column ``cols [N, c]`` in the first contraction, given the count ``base`` that a well-behaved
+    column gets (SketchRunner.cross_digits: 1 from N = 16 384 on).  One digit scales a column by 126 / max|w|: its quantisation
+    error is 0.0023 max|w| per sample (uniform within half a step), i.e. 0.0023 x (max|w| / rms(w)) of the column's own scale --
+    1 % for a Gaussian covariate (max / rms = 5 at N = 500k), but a skewed or squared covariate with max / rms in the hundreds
+    would be quantised to zeros almost everywhere (advisor, round 3).  So: one digit only up to max / rms = 8 (<= 2 % of the
+    rms), two digits (error x 1 / 256) up to 2048, three beyond.  A column that one digit holds EXACTLY (an intercept, 0 / 1
+    indicators however rare, counts 0 / 1 / 2 / 3) keeps one digit whatever its ratio."""
+    cols = np.asarray(cols, np.float64)
+    out = np.full(cols.shape[1], int(base), np.int64)
+    if base >= 3:
+        return out
+    mx = np.abs(cols).max(axis=0)
+    rms = np.sqrt(np.mean(cols * cols, axis=0))
+    for j in range(cols.shape[1]):
+        if not (mx[j] > 0) or not np.isfinite(mx[j]):
+            continue
+        q = cols[:, j].astype(np.float32) * np.float32(126.0 / mx[j])
+        if np.array_equal(q, np.rint(q)):
+            continue                                     # exact in one digit
+        ratio = mx[j] / max(rms[j], 1e-300)
+        need = 1 if ratio <= 8.0 else (2 if ratio <= 2048.0 else 3)
+        out[j] = max(int(base), need)
+    return out
+
+
+def plan_passes(k: int, n_groups: int, n_norm: int, cross=(), cross_digits: int = 3, wide: bool = False, cross_rows=None):
     """Distribute ``n_groups`` groups of ``k`` sketch columns (Z, UZ, e.Z, e.UZ) and ``n_norm`` norm columns (all in
     pass 0) over engine passes of at most 30 right-hand columns.  A group stays whole when it fits into the current
     pass or into a fresh one; only groups wider than a pass (num_random_vec > 30 - n_norm) are split.
@@ -133,25 +159,28 @@ def plan_passes(k: int, n_groups: int, n_norm: int, cross=(), cross_digits: int 
     pass); then the result is ``(passes, cross_at)`` with ``cross_at[i] = (pass, first cross column of that pass)`` -- the
     first pass with room, or a pass of its own (one GEMM 1 over the genotypes, no GEMM 2).  ``wide``: int8 engines, which
     take up to 46 columns as long as the packed digit rows of the pass fit six 16-row tiles (``cross_digits`` rows per cross
-    column: GENIE G x E + 10 one-digit covariates = 20 + 2 + 20 columns = 87 rows in ONE pass)."""
+    column: GENIE G x E + 10 one-digit covariates = 20 + 2 + 20 columns = 87 rows in ONE pass).  ``cross_rows``: the packed digit
+    rows of each cross group where its columns carry different digit counts (column_digits; default ``cross_digits`` x size)."""
     if cross:
         passes = plan_passes(k, n_groups, n_norm)
         cap = MAX_ENGINE_COLS_I8 if wide else MAX_ENGINE_COLS
         cols3 = [sum(nc for _, _, nc in ch) + (n_norm if pi == 0 else 0) for pi, ch in enumerate(passes)]    # three-digit columns
-        used, cross_at = [0] * len(passes), []
+        used, used_rows, cross_at = [0] * len(passes), [0] * len(passes), []
+        rows_of = [int(r) for r in cross_rows] if cross_rows is not None else [cross_digits * c for c in cross]
 
-        def fits(pi, c):
-            rows = 3 * cols3[pi] + cross_digits * (used[pi] + c) + 1
+        def fits(pi, c, r):
+            rows = 3 * cols3[pi] + used_rows[pi] + r + 1
             return cols3[pi] + used[pi] + c <= cap and (not wide or rows <= MAX_DIGIT_ROWS_I8)
-        for c in cross:
-            if c > MAX_ENGINE_COLS or (wide and cross_digits * c + 1 > MAX_DIGIT_ROWS_I8):
+        for c, r in zip(cross, rows_of):
+            if c > MAX_ENGINE_COLS or (wide and r + 1 > MAX_DIGIT_ROWS_I8):
                 raise ValueError(f"a cross group of {c} columns does not fit one engine pass")
-            pi = next((i for i in range(len(passes)) if fits(i, c)), None)
+            pi = next((i for i in range(len(passes)) if fits(i, c, r)), None)
             if pi is None:
-                passes.append([]); cols3.append(0); used.append(0)
+                passes.append([]); cols3.append(0); used.append(0); used_rows.append(0)
                 pi = len(passes) - 1
             cross_at.append((pi, used[pi]))
             used[pi] += c
+            used_rows[pi] += r
         return passes, cross_at
     passes, free = [[]], [MAX_ENGINE_COLS - n_norm]
     for g in range(n_groups):
@@ -176,14 +205,14 @@ def n_engines_needed(k: int, use_cov: bool, has_gxe: bool) -> int:
     return len(plan_passes(k, (2 if use_cov else 1) * (2 if has_gxe else 1), 2 if has_gxe else 1))
 
 
-def cross_columns_pay(k: int, c: int, has_gxe: bool, cross_digits: int = 3, wide: bool = False) -> bool:
+def cross_columns_pay(k: int, c: int, has_gxe: bool, cross_digits: int = 3, wide: bool = False, cross_rows=None) -> bool:
     """Whether the covariates go in as CROSS columns (c more columns in GEMM 1, their c x c Gram per (block, bin) out)
     instead of the k sketch columns U Z (k more columns in both contractions, [k, N] rows per (block, bin) out): when that
     takes no more passes over the genotypes than the materialised form."""
     if c < 1 or c > MAX_ENGINE_COLS:
         return False
     g = 2 if has_gxe else 1
-    passes, _ = plan_passes(k, g, g, cross=[c] * g, cross_digits=cross_digits, wide=wide)
+    passes, _ = plan_passes(k, g, g, cross=[c] * g, cross_digits=cross_digits, wide=wide, cross_rows=cross_rows)
     return len(passes) <= n_engines_needed(k, True, has_gxe)
 
 
@@ -276,8 +305,17 @@ class SketchRunner:
         # instead (the reference's own arrays; block-wise XXUz tests, or more covariates than a pass has room for).
         self.cross_digits = int(cross_digits) if cross_digits else (1 if self.N >= 16384 else 3)      # see below
         self.wide_cols = getattr(self.eng, "precision", "") in ("i8x3", "i8f16")       # int8 engines: up to 46 columns per pass
+        # per column: a covariate whose largest value is far above its rms takes more digits than the rest (column_digits); a
+        # count given by the caller applies to every column
+        self.cross_col_digits = {}
+        if self.cov is not None:
+            forced = bool(cross_digits)
+            dg = lambda cols: (np.full(cols.shape[1], self.cross_digits, np.int64) if forced else column_digits(cols, self.cross_digits))
+            self.cross_col_digits["W"] = dg(self.cov)
+            if self.n_gxe:
+                self.cross_col_digits["eW"] = dg(self.cov * self.env[:, None])
         self.cross = (self.cov is not None and not materialize_xxuz and
-                      cross_columns_pay(self.k, self.cov.shape[1], self.n_gxe > 0, self.cross_digits, self.wide_cols))
+                      cross_columns_pay(self.k, self.cov.shape[1], self.n_gxe > 0, self.cross_digits, self.wide_cols, self._cross_rows()))
         # int8 digits of the covariate (cross) columns in the first contraction (PYRHE_COL_DIGITS): S only enters the O(c / N) terms
         # of T.  Measured on the CPU stand-in (N = 500 / 2000, 6 covariates, 3 bins): two digits move sigma^2 / SE by 4e-8 /
         # 8e-8 at N = 500; ONE digit by 6e-6 / 1e-5 at N = 500, 2e-7 / 1.6e-6 at N = 2000 (it falls as 1 / N^2: below 3e-8
@@ -294,7 +332,7 @@ class SketchRunner:
         # of their own where the engine allows (_windows); PYRHE_BATCH_PIECES=0: the engine's own chunking / one call per piece
         self.batch_pieces = os.environ.get("PYRHE_BATCH_PIECES", "1") != "0"
         self.force_tk_proj = False    # tests: <XXz, U Z> through the covariate projections even where the U Z row has room (_loo_systems)
-        self.norm_digits = 3          # int8 digits of the phenotype columns in GEMM 1 (precision experiments: tools/r3_ydigits.sh)
+        self.norm_digits = 3          # int8 digits of the phenotype columns in GEMM 1 (precision experiments: tools/ab.sh [ydigits])
         self.one_slot = False         # this trait group keeps ONE block slot and re-sketches in pass 2 (begin_trait decides)
         self.row_limit = None         # rows one engine call may address; None = from the engine's 32-bit byte offsets
         self._span_ok = None          # see _lists_may_span_calls
@@ -302,6 +340,10 @@ class SketchRunner:
         self._stats = None
         self._check_missing = True
         self.timings = {}
+
+    def _cross_rows(self):
+        """Packed digit rows of the cross groups W [, e.W] (plan_passes)."""
+        return [int(self.cross_col_digits[n_].sum()) for n_ in (("W", "eW") if self.n_gxe else ("W",))]
 
     # ---- padding helpers: kept samples -> their original positions, zeros elsewhere
     def _pad_cols(self, t: torch.Tensor) -> torch.Tensor:
@@ -348,7 +390,7 @@ class SketchRunner:
         n_norm_all = sum(n.shape[0] for n in norms)
         if cgroups:
             passes, cross_at = plan_passes(k, len(groups), n_norm_all, cross=[g.shape[0] for g in cgroups],
-                                           cross_digits=self.cross_digits, wide=self.wide_cols)
+                                           cross_digits=self.cross_digits, wide=self.wide_cols, cross_rows=self._cross_rows())
         else:
             passes, cross_at = plan_passes(k, len(groups), n_norm_all), []
         if len(passes) > len(self.engs):
@@ -357,7 +399,24 @@ class SketchRunner:
         # where each logical group lives: a list of chunks (pass, first engine column, first group column s0, count);
         # norm columns: (pass, column).  `breaks`: the common refinement of all chunk boundaries (pass 2 walks it).
         self.loc = {n: [] for n in names}
-        self.cross_loc = {n: (cp, c0, cgroups[i].shape[0]) for i, (n, (cp, c0)) in enumerate(zip(cnames, cross_at))}
+        # cross columns of a pass in the order the engine wants them: digit counts must not grow with the column index, so the
+        # columns of all cross groups of the pass are sorted by their digits (stable); cross_loc[name] = (pass, where the
+        # group's columns sit in that order)
+        self.cross_loc, cross_order = {}, {}
+        for pi in range(len(passes)):
+            mine = [i for i, (cp, _) in enumerate(cross_at) if cp == pi]
+            if not mine:
+                continue
+            dg = np.concatenate([self.cross_col_digits[cnames[i]] for i in mine])
+            order = np.argsort(-dg, kind="stable")
+            pos = np.empty_like(order)
+            pos[order] = np.arange(len(order))
+            cross_order[pi] = (order, dg[order])
+            o = 0
+            for i in mine:
+                c_ = cgroups[i].shape[0]
+                self.cross_loc[cnames[i]] = (pi, torch.from_numpy(pos[o:o + c_].astype(np.int64)).to(self.device))
+                o += c_
         self.pass_shapes, self.pass_cross = [], []
         breaks = {0, k}
         for pi, chunks in enumerate(passes):
@@ -371,8 +430,11 @@ class SketchRunner:
             nm = torch.cat(norms, dim=0).to(torch.float32) if pi == 0 else None
             cr = [cgroups[i] for i, (cp, _) in enumerate(cross_at) if cp == pi]
             if cr:
-                self.engs[pi].set_rhs(sk, nm, self.keep, cross_cols=torch.cat(cr, dim=0).to(torch.float32),
-                                      cross_digits=self.cross_digits, **({"norm_digits": self.norm_digits} if self.norm_digits != 3 else {}))
+                order, dg = cross_order[pi]
+                uniform = int(dg.min()) == int(dg.max())
+                self.engs[pi].set_rhs(sk, nm, self.keep, cross_cols=torch.cat(cr, dim=0)[torch.from_numpy(order).to(self.device)].to(torch.float32),
+                                      cross_digits=int(dg[0]) if uniform else [int(d_) for d_ in dg],
+                                      **({"norm_digits": self.norm_digits} if self.norm_digits != 3 else {}))
             else:
                 self.engs[pi].set_rhs(sk, nm, self.keep, **({"norm_digits": self.norm_digits} if self.norm_digits != 3 else {}))
             self.pass_shapes.append((col, n_norm_all if pi == 0 else 0))
@@ -466,7 +528,7 @@ class SketchRunner:
         # launch).  Cohorts below 196 608 samples gain from that -- GEMM 1 gets rows enough for the 128-row kernel and long launches:
         # N = 50k with 8 bins 5.62 -> 4.86 ms per pass, with 4 bins 4.07 -> 3.62, N = 100k with 8 bins 7.88 -> 7.35 -- and take WHOLE
         # tables (a last table of fewer segments is a short GEMM 2 launch); at N = 500k GEMM 1 gains less than GEMM 2 loses (8 bins +
-        # covariates 56.9 -> 57.6 ms, 32 bins 87.7 -> 88.2, 1000-SNP blocks 57.5 -> 57.6; tools/r3_s47.sh): one table per call there.
+        # covariates 56.9 -> 57.6 ms, 32 bins 87.7 -> 88.2, 1000-SNP blocks 57.5 -> 57.6; tools/ab.sh [s47]): one table per call there.
         by_lists = max(1, MAX_SEGMENTS // max(self.plan.n_bin, 1))
         if (self.n_pad < 192 * 1024 or os.environ.get("PYRHE_WHOLE_TABLES") == "1") and os.environ.get("PYRHE_ONE_TABLE") != "1":
             by_lists *= max(1, min(by_entries, max(by_bytes, 1)) // by_lists)
@@ -559,7 +621,7 @@ class SketchRunner:
         lim = self._row_limit()
         # Where the pieces of a call go in together as list WINDOWS (_window_calls_ok), no list of a piece exceeds what one kernel
         # chunk takes of a list (SEG_CAP): a longer list would end the chunk -- one GEMM 1 launch per 15 104 entries, N = 500k with
-        # blocks of 16 667 ... 33 333 SNPs: GEMM 1 25.6 - 27.1 ms per pass against 23.1 (tools/r3_s38.sh).
+        # blocks of 16 667 ... 33 333 SNPs: GEMM 1 25.6 - 27.1 ms per pass against 23.1 (tools/ab.sh [s38]).
         lim_list = SEG_CAP if self._window_calls_ok() else None
         if e - s <= lim and (lim_list is None or e - s <= lim_list):
             return None                                             # (the common case, asked for every block of every call: no work here)
@@ -763,7 +825,8 @@ class SketchRunner:
             used = sum(nc for _, _, nc in plan_passes(self.k, per, per)[0])
             best = 1
             for nt in range(1, (MAX_ENGINE_COLS - used) // per + 1):
-                if len(plan_passes(self.k, per, per * nt, cross=[c] * per, cross_digits=self.cross_digits, wide=self.wide_cols)[0]) <= len(self.engs):
+                if len(plan_passes(self.k, per, per * nt, cross=[c] * per, cross_digits=self.cross_digits, wide=self.wide_cols,
+                                   cross_rows=self._cross_rows())[0]) <= len(self.engs):
                     best = nt
             return best
         n_groups = (2 if self.cov is not None else 1) * (2 if self.n_gxe else 1)
@@ -803,6 +866,11 @@ class SketchRunner:
         self.blocks_sk = self.blocks_nm = self.blocks_skd = self.blocks_nmd = self.blocks_cr = self.blocks_crd = None
         self.one_slot = bool(self.recompute_pass2)
         store_bytes = jl * nb * sum(ns for ns, _ in shapes) * self.n_pad * 4 * (2 if self.dom else 1)
+        # beside the store: the float64 totals, and with several ranks the exchange's accumulator + two rounds in flight
+        # (_pass1_exchange_rounds), each once more for the (jn - j)-weighted totals of quirk Q4
+        tot_bytes = nb * sum(ns for ns, _ in shapes) * self.n_pad * 8 * (2 if self.dom else 1)
+        q4 = self.cov is not None and self.streaming and self.compat == "reference"
+        store_bytes += tot_bytes * (3 if self.collective else 1) * (2 if q4 else 1)
         if not self.one_slot and dev.type == "cuda":
             torch.cuda.empty_cache()
             free = torch.cuda.mem_get_info(dev)[0]
@@ -829,8 +897,8 @@ class SketchRunner:
         """S_a = W^T X_a X_a^T W ``[..., ne_g, c, c]`` of the genotype-derived estimates (G bins, then dominance or G x E
         bins) from the per-pass Gram matrices of the cross columns ``[..., nbin, n_cross_p, n_cross_p]``."""
         def grp(lst, name):
-            p_, o, c = self.cross_loc[name]
-            return lst[p_][..., o:o + c, o:o + c]
+            p_, idx = self.cross_loc[name]
+            return lst[p_][..., idx[:, None], idx[None, :]]
         S = grp(cr_list, "W")
         if self.dom:
             S = torch.cat([S, grp(crd_list, "W")], dim=-3)
@@ -897,54 +965,105 @@ class SketchRunner:
         C = (e32 * (e32 * self.UZ64.to(f32))).to(f64)[None] if self.cov is not None else None
         return A, C, r
 
-    def _pass1_exchange_rounds(self, q4, w, reduce_async, z_part, handles):
-        """Several ranks: sketch the local blocks and all-reduce the float64 partial totals of every ENGINE CALL (a batch of
-        blocks) as soon as the call is enqueued -- RCCL moves them over xGMI on its own stream while the next call's kernels run;
-        only the last call's exchange is exposed (8 GPUs, 8 bins + covariates: two calls of 8 + 5 blocks per rank, 320 MB each).
-        The whole-data totals are the sums of the reduced partials (float64: any order agrees to 1e-16).  Every rank takes part in
-        ceil(largest shard / blocks per call) rounds, in the same order; a rank with fewer calls (or no block) contributes zeros.
-        Returns (tot_sk, tot_skd, w_sk, w_skd): per-pass totals, their dominance twins, the (jn - j)-weighted XXz of quirk Q4."""
-        jn, dev, f64 = self.plan.n_jack, self.device, torch.float64
-        names = ("Z", "eZ") if self.n_gxe else ("Z",)
-        part = {"sk": [[] for _ in self.blocks_sk], "skd": [[] for _ in self.blocks_sk],
-                "w": {n_: [[] for _ in self.loc[n_]] for n_ in names}, "wd": {n_: [[] for _ in self.loc[n_]] for n_ in names}}
-        rounds = [0]
-        zero = lambda b: torch.zeros(b.shape[1:], dtype=f64, device=dev)
+    # Exchange rounds of one sketch pass at most (several ranks): a rank's engine calls are grouped into that many all-reduces.
+    MAX_EXCHANGE_ROUNDS = 4
 
-        def exchange(jl0, n):
-            """One round: the partial totals of local blocks jl0 .. jl0 + n - 1 (n = 0: zeros)."""
-            rounds[0] += 1
+    def _exchange_plan(self):
+        """(engine calls per exchange round, rounds) -- the same on every rank: the largest shard's calls, grouped so that a pass
+        has at most MAX_EXCHANGE_ROUNDS rounds (wire bytes and buffers must not grow with the calls per rank: 2 GPUs with 32 bins
+        at N = 500k make 25 calls of 2 blocks each)."""
+        largest = max(b_ - a_ for a_, b_ in shard_ranges(self.plan.n_jack, self.world))
+        n_calls = -(-largest // max(1, self._blocks_per_call()))
+        stride = max(1, -(-n_calls // self.MAX_EXCHANGE_ROUNDS))
+        return stride, -(-n_calls // stride)
+
+    def _pass1_exchange_rounds(self, q4, w, z_part):
+        """Several ranks: sketch the local blocks and all-reduce float64 partial totals while the sketch runs.  The engine calls
+        of a rank (a call = a batch of blocks) are grouped into at most MAX_EXCHANGE_ROUNDS rounds (_exchange_plan); behind the
+        last call of a round the partial totals of the round's blocks are summed (pyrhe_sum_blocks over their slice of the
+        store) and all-reduced asynchronously -- RCCL moves them over xGMI on its own stream while the next calls' kernels run,
+        only the last round's exchange is exposed (8 GPUs, 8 bins + covariates: two calls of 8 + 5 blocks per rank = two rounds
+        of 320 MB).  At most TWO rounds are in flight: before a third is issued the oldest is waited for and folded into ONE
+        accumulator per bucket, so the memory of the exchange is three times the totals whatever the number of calls
+        (advisor, round 3: it used to keep every round's buffers until the end).  The whole-data totals are the sums of the
+        reduced partials in round order (float64: any grouping agrees to 1e-16).  Every rank takes part in the same rounds in
+        the same order; a rank with fewer calls (or no block) contributes zeros.
+        Returns (tot_sk, tot_skd, w_sk, w_skd): per-pass totals, their dominance twins, the (jn - j)-weighted XXz of quirk Q4."""
+        dev, f64 = self.device, torch.float64
+        names = ("Z", "eZ") if self.n_gxe else ("Z",)
+        stride, n_rounds = self._exchange_plan()
+        zero = lambda b: torch.zeros(b.shape[1:], dtype=f64, device=dev)
+        acc, inflight = {}, []
+        st = {"calls": 0, "start": 0, "end": 0, "rounds": 0}
+
+        def fold_oldest():
+            hs, bufs = inflight.pop(0)
+            for h in hs:
+                h.wait()
+            for key, t in bufs:
+                if key in acc:
+                    acc[key] += t
+                else:
+                    acc[key] = t
+
+        def issue(jl0, jl1):
+            """One round: the partial totals of local blocks jl0 .. jl1 - 1 (none: zeros)."""
+            while len(inflight) >= 2:
+                fold_oldest()
+            n = jl1 - jl0
+            hs, bufs = [], []
+
+            def send(key, t):
+                h = self._allreduce(t, async_op=True)
+                if h is not None:
+                    hs.append(h)
+                bufs.append((key, t))
             for p_, b in enumerate(self.blocks_sk):
                 if not b.shape[2]:
                     continue                                   # a pass without sketch columns (cross columns alone)
-                part["sk"][p_].append(reduce_async(self.eng.sum_blocks(b[jl0:jl0 + n]) if n else zero(b)))
+                send(("sk", p_), self.eng.sum_blocks(b[jl0:jl1]) if n else zero(b))
                 if self.dom:
                     bd = self.blocks_skd[p_]
-                    part["skd"][p_].append(reduce_async(self.eng.sum_blocks(bd[jl0:jl0 + n]) if n else zero(bd)))
+                    send(("skd", p_), self.eng.sum_blocks(bd[jl0:jl1]) if n else zero(bd))
             if q4:
                 for key, store in (("w", self.blocks_sk), ("wd", self.blocks_skd if self.dom else None)):
                     if store is None:
                         continue
-                    wt = z_part([(self.eng.sum_blocks(b[jl0:jl0 + n], w[jl0:jl0 + n].contiguous()) if n else zero(b)) if b.shape[2] else None
+                    wt = z_part([(self.eng.sum_blocks(b[jl0:jl1], w[jl0:jl1].contiguous()) if n else zero(b)) if b.shape[2] else None
                                  for b in store])
                     for n_, chunks in wt.items():
                         for i_, t in enumerate(chunks):
-                            part[key][n_][i_].append(reduce_async(t))
-        self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0, after_call=exchange)
-        largest = max(b_ - a_ for a_, b_ in shard_ranges(jn, self.world))
-        for _ in range(rounds[0], -(-largest // max(1, self._blocks_per_call()))):
-            exchange(0, 0)
-        for h in handles:
-            h.wait()
-        handles.clear()
-        total = lambda lst, like: (torch.stack(lst).sum(dim=0) if len(lst) > 1 else lst[0]) if lst else zero(like)
-        tot_sk = [total(part["sk"][p_], b) for p_, b in enumerate(self.blocks_sk)]
-        tot_skd = [total(part["skd"][p_], b) for p_, b in enumerate(self.blocks_skd)] if self.dom else None
+                            send((key, n_, i_), t)
+            inflight.append((hs, bufs))
+            st["rounds"] += 1
+            self.timings["exchange_rounds"] = st["rounds"]
+
+        def after_call(jl0, n):
+            st["calls"] += 1
+            st["end"] = jl0 + n
+            if st["calls"] % stride == 0:
+                issue(st["start"], st["end"])
+                st["start"] = st["end"]
+        self.sketch_local_blocks(self.blocks_sk, self.blocks_nm, pass_index=0, after_call=after_call)
+        if st["end"] > st["start"]:
+            issue(st["start"], st["end"])
+        if st["rounds"] > n_rounds:
+            raise RuntimeError(f"{st['rounds']} exchange rounds on this rank, {n_rounds} planned: the ranks would not meet")
+        while st["rounds"] < n_rounds:
+            issue(0, 0)
+        while inflight:
+            fold_oldest()
+        tot_sk = [acc.get(("sk", p_), None) if b.shape[2] else None for p_, b in enumerate(self.blocks_sk)]
+        tot_sk = [t if t is not None else zero(b) for t, b in zip(tot_sk, self.blocks_sk)]
+        tot_skd = None
+        if self.dom:
+            tot_skd = [acc[("skd", p_)] if ("skd", p_) in acc else zero(b) for p_, b in enumerate(self.blocks_skd)]
         w_sk = w_skd = None
         if q4:
             like = lambda n_, i_: self.blocks_sk[self.loc[n_][i_][0]][:, :, :self.loc[n_][i_][3]]
-            w_sk = {n_: [total(lst, like(n_, i_)) for i_, lst in enumerate(part["w"][n_])] for n_ in names}
-            w_skd = {n_: [total(lst, like(n_, i_)) for i_, lst in enumerate(part["wd"][n_])] for n_ in names} if self.dom else None
+            get = lambda key, n_, i_: acc[(key, n_, i_)] if (key, n_, i_) in acc else zero(like(n_, i_))
+            w_sk = {n_: [get("w", n_, i_) for i_ in range(len(self.loc[n_]))] for n_ in names}
+            w_skd = {n_: [get("wd", n_, i_) for i_ in range(len(self.loc[n_]))] for n_ in names} if self.dom else None
         return tot_sk, tot_skd, w_sk, w_skd
 
     def pass1(self):
@@ -982,7 +1101,7 @@ class SketchRunner:
 
         tot_skd = tot_nmd = w_sk = w_skd = tot_crd = None
         if not self.one_slot and self.collective:
-            tot_sk, tot_skd, w_sk, w_skd = self._pass1_exchange_rounds(q4, w, reduce_async, z_part, handles)
+            tot_sk, tot_skd, w_sk, w_skd = self._pass1_exchange_rounds(q4, w, z_part)
             tot_nm = [b[:jl].sum(dim=0) for b in self.blocks_nm]
             tot_cr = [b[:jl].sum(dim=0) for b in self.blocks_cr]
             if self.dom:

@@ -27,6 +27,18 @@ class CpuStubEngine:
         self.sk = None if sketch_cols is None else sketch_cols.double().numpy()
         self.nm = None if norm_cols is None else norm_cols.double().numpy()
         self.cr = None if cross_cols is None else cross_cols.double().numpy()
+        if self.cr is not None:
+            # what the int8 first contraction sees of a cross column: `nd` balanced radix-256 digits of w * 126 / max|w|
+            # (the engine's prep_rimg_i8_kernel) = w rounded to the nearest multiple of max|w| / (126 * 256^(nd-1)); three
+            # digits are the float32 value itself
+            nds = list(cross_digits) if isinstance(cross_digits, (list, tuple, np.ndarray)) else [cross_digits] * len(self.cr)
+            assert len(nds) == len(self.cr) and all(a >= b for a, b in zip(nds, nds[1:])), "digit counts must not grow with the column index"
+            self.cross_digits = [int(d) for d in nds]
+            for j, nd in enumerate(self.cross_digits):
+                mx = np.abs(self.cr[j]).max()
+                if nd < 3 and mx > 0:
+                    step = mx / (126.0 * 256.0 ** (nd - 1))
+                    self.cr[j] = np.rint(self.cr[j] / step) * step
         self.n_cross = 0 if self.cr is None else self.cr.shape[0]
         self.keep = keep.numpy().astype(bool)
         self.n_sketch = 0 if self.sk is None else self.sk.shape[0]

@@ -125,3 +125,73 @@ def test_rhe_dom_with_cross_columns_matches_the_reference_and_the_materialised_f
     sig = est.solve_all(a.T, a.q)
     assert np.allclose(sig[-1], z["ref_t0_res_sigma_ests_total"], rtol=2e-6)
     assert np.allclose(est.jackknife_se(sig[:-1], p.n_jack), z["ref_t0_res_sig_errs"], rtol=2e-5)
+
+
+def test_digits_per_cross_column_follow_the_dynamic_range():
+    """column_digits: one int8 digit only for columns it represents to <= 2 % of their rms (max / rms <= 8) or exactly (an
+    intercept, indicators however rare, small counts); a skewed covariate takes two, an extreme one three; cohorts below 16 384
+    samples (base 3) keep three everywhere (advisor, round 3: one digit for every covariate quantised heavy-tailed columns to
+    zeros almost everywhere)."""
+    from pyrhe_amd.streaming import column_digits, plan_passes
+    rng = np.random.default_rng(5)
+    n = 20000
+    gauss = rng.normal(size=n)
+    cols = np.stack([np.ones(n), gauss, (rng.random(n) < 0.001).astype(float), rng.integers(0, 3, n).astype(float),
+                     np.exp(2.5 * gauss), gauss ** 2, np.where(np.arange(n) == 7, 1e6, gauss), rng.integers(0, 5, n) * 0.37], axis=1)
+    got = column_digits(cols, 1)
+    ratio = np.abs(cols).max(axis=0) / np.sqrt((cols ** 2).mean(axis=0))
+    # (max / rms <= sqrt(N): a single outlier of any size stays below the 2048 of the third digit until N = 4.2 M)
+    assert ratio[4] > 8 and ratio[5] > 8 and 100 < ratio[6] <= np.sqrt(n) and ratio[7] <= 8
+    assert list(got) == [1, 1, 1, 1, 2, 2, 2, 1]
+    assert list(column_digits(cols, 3)) == [3] * 8 and list(column_digits(cols, 2)) == [2] * 8
+    big = np.zeros((5_000_000, 1))
+    big[::2] = 1e-3
+    big[7] = 5.0
+    assert list(column_digits(big, 1)) == [3]                   # max / rms = 2132
+    # the planner counts the rows the columns really take: 10 probes + phenotype + 10 covariates, one of them on two digits,
+    # still fit three tiles (45 packed digit rows); all of them on three digits do not fit one pass beside the sketch columns
+    passes, at = plan_passes(10, 1, 1, cross=[10], wide=True, cross_rows=[11])
+    assert len(passes) == 1 and at == [(0, 0)]
+    passes, at = plan_passes(10, 2, 2, cross=[10, 10], wide=True, cross_rows=[12, 20])     # 66 + 32 + 1 = 99 rows: the second group moves on
+    assert len(passes) == 2 and at == [(0, 0), (1, 0)]
+
+
+def test_heavy_tailed_covariate_gets_more_digits_and_keeps_the_systems():
+    """A covariate set with an intercept, a Gaussian, a log-normal (max / rms = 40) and a rare indicator at N = 16 500 on the
+    stand-in engine, which quantises the cross columns like the int8 first contraction: with the automatic per-column digits
+    the systems agree with the all-three-digits run far better than with ONE digit forced on every column, the engine is
+    handed the columns sorted by their digits, and the cross Grams come back in the covariates' own order."""
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner
+    from oracle import fixtures
+    from oracle import rhe_oracle as O
+    from tests.cpu_stub_engine import CpuStubEngine
+    n, m, jn, k = 16500, 48, 3, 4
+    c = fixtures.make_cohort("heavy", n, m, seed=11, nbin=2, with_cov=0)
+    rng = np.random.default_rng(9)
+    g = rng.normal(size=n)
+    cov = np.stack([np.ones(n), np.exp(2.0 * g), rng.normal(size=n), (rng.random(n) < 0.002).astype(float)], axis=1)
+    y = c.pheno[:, 0] + 0.3 * cov[:, 1] / cov[:, 1].std()
+    y = y - y.mean()
+    plan = BlockPlan(c.annot, jn)
+    Z = O.make_probe_vectors(0, n, k)
+    out = {}
+    for tag, digits in (("auto", None), ("three", 3), ("one", 1)):
+        eng = CpuStubEngine(n, n)
+        geno = torch.zeros((c.packed.shape[0], eng.pitch), dtype=torch.uint8)
+        geno[:, : c.packed.shape[1]] = torch.from_numpy(c.packed.copy())
+        r = SketchRunner(eng, geno, plan, (0, jn), n_orig=n, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=False, compat="fixed",
+                         cross_digits=digits)
+        assert r.cross
+        out[tag] = r.run_trait(y)
+        if tag == "auto":
+            assert list(r.cross_col_digits["W"]) == [1, 2, 1, 1] and r.cross_digits == 1
+            assert eng.cross_digits == [2, 1, 1, 1]                              # the log-normal column first
+            assert r.cross_loc["W"][1].tolist() == [1, 0, 2, 3]
+            S = r._cross_grams([b.sum(dim=0) for b in r.blocks_cr])              # [nbin, c, c] in the covariates' order
+            Wq = torch.from_numpy(eng.cr[r.cross_loc["W"][1].numpy()][:, :n])    # what the engine was given, re-ordered back
+            assert torch.allclose(Wq[[0, 2, 3]], torch.from_numpy(cov.T[[0, 2, 3]]), rtol=0, atol=np.abs(cov[:, 2]).max() / 250)
+            assert S.shape == (2, 4, 4) and torch.allclose(S, S.transpose(1, 2))
+    scale = np.abs(out["three"].T).max()
+    d_auto = np.abs(out["auto"].T - out["three"].T).max() / scale
+    d_one = np.abs(out["one"].T - out["three"].T).max() / scale
+    assert d_auto <= 2e-8 and d_auto < 0.2 * d_one, (d_auto, d_one)

@@ -127,7 +127,8 @@ def _synth_worker(rank, world, port, shape, out_dir):
     try:
         runner, y, local = _synth_runner(*shape)
         sysm = runner.run_trait(y)
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), T=sysm.T, q=sysm.q, M=sysm.M, local=np.asarray(local))
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), T=sysm.T, q=sysm.q, M=sysm.M, local=np.asarray(local),
+                 rounds=int(runner.timings.get("exchange_rounds", 0)))
     finally:
         dist.destroy_process_group()
 
@@ -140,7 +141,10 @@ def _synth_worker(rank, world, port, shape, out_dir):
                                          # four blocks per engine call: 13-block ranks exchange in 4 rounds (4, 4, 4, 1), the 9-block rank's
                                          # fourth round carries zeros; quirk Q4's weighted totals travel per call too
                                          (8, (96, 300, 100, 2, 3, "reference", 4)),
-                                         (4, (64, 90, 3, 2, 2, "fixed", 1))])         # a rank without blocks in a 1-round exchange
+                                         (4, (64, 90, 3, 2, 2, "fixed", 1)),          # a rank without blocks in a 1-round exchange
+                                         # 50 blocks per rank in calls of 2 = 25 calls: grouped into 4 rounds of 7, 7, 7, 4 calls
+                                         # (SketchRunner.MAX_EXCHANGE_ROUNDS: buffers and wire bytes do not grow with the calls)
+                                         (2, (96, 300, 100, 2, 3, "reference", 2))])
 def test_many_ranks_uneven_and_empty_shards_equal_one_rank(world, shape, tmp_path):
     from pyrhe_amd.streaming import shard_ranges
     mp.spawn(_synth_worker, args=(world, _free_port(), shape, str(tmp_path)), nprocs=world, join=True)
@@ -151,6 +155,12 @@ def test_many_ranks_uneven_and_empty_shards_equal_one_rank(world, shape, tmp_pat
     assert sum(sizes) == jn and (world <= jn or 0 in sizes)
     for p in parts[1:]:
         assert np.array_equal(parts[0]["T"], p["T"]) and np.array_equal(parts[0]["q"], p["q"])     # every rank holds all systems
+    from pyrhe_amd.streaming import SketchRunner
+    per_call = shape[6] if len(shape) > 6 else None
+    if per_call:
+        calls = -(-max(sizes) // per_call)
+        want = -(-calls // -(-calls // SketchRunner.MAX_EXCHANGE_ROUNDS))
+        assert [int(p["rounds"]) for p in parts] == [want] * world and want <= SketchRunner.MAX_EXCHANGE_ROUNDS
     runner, y, _ = _synth_runner(*shape)                                                            # world = 1 in this process
     one = runner.run_trait(y)
     assert np.array_equal(one.M, parts[0]["M"])

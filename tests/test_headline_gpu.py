@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 SEED = 20251212          # bench.py's SYNTH_SEED
 
 
-def _setup(n, m, jn, k, nbin=1, n_cov=0, row0=0, materialize=False, genie=None, cross_digits=None, dom=False):
+def _setup(n, m, jn, k, nbin=1, n_cov=0, row0=0, materialize=False, genie=None, cross_digits=None, dom=False, heavy=False):
     from pyrhe_amd import engine
     from pyrhe_amd.streaming import BlockPlan, SketchRunner, engine_capacity, n_engines_needed
     dev = torch.device("cuda", 0)
@@ -41,6 +41,11 @@ def _setup(n, m, jn, k, nbin=1, n_cov=0, row0=0, materialize=False, genie=None, 
     cov = None
     if n_cov:
         cov = np.concatenate([np.ones((n, 1)), np.random.default_rng(2).normal(size=(n, n_cov - 1))], axis=1)
+        if heavy:            # a log-normal covariate (max / rms ~ 50) that also drives the phenotype, and a rare indicator
+            cov[:, 1] = np.exp(2.0 * cov[:, 1])
+            cov[:, 2] = (np.random.default_rng(4).random(n) < 0.002).astype(np.float64)
+            y = y + 0.5 * cov[:, 1] / cov[:, 1].std()
+            y -= y.mean()
     env = None
     kw = {}
     if genie:
@@ -208,6 +213,18 @@ def test_c4_8bins_covariates_at_n500k_vs_oracle():
     p, runner, engs = _setup(500_000, 960, 3, 10, nbin=8, n_cov=10, row0=11)
     assert runner.cross and runner.cross_digits == 1
     _check(p, runner, engs, {"gemm1": 203, "gemm2": 11, "segmented": True, "g2_merged": 7}, blocks_per_call=3, with_exact=False)
+
+
+def test_heavy_tailed_covariates_get_their_digits_vs_oracle():
+    """Covariates with a log-normal column and a rare 0 / 1 indicator at N = 20 000 (one int8 digit per cross column is the
+    default from N = 16 384 on): the log-normal column -- max / rms = 50, one digit would quantise nearly all of it to zero --
+    takes two digits (streaming.column_digits), the indicator is exact in one; sigma^2 and SE within 1e-5 of the oracle, the
+    projections W^T XXUz per block within the 8-bit quantisation of the Gaussian columns (advisor, round 3)."""
+    p, runner, engs = _setup(20_000, 600, 3, 10, nbin=2, n_cov=5, row0=71, heavy=True)
+    assert runner.cross and list(runner.cross_col_digits["W"]) == [1, 2, 1, 1, 1]
+    runner.begin_trait(p.pheno[:, 0], check_missing=False)
+    assert int(engs[0].lib.pyrhe_engine_info(engs[0]._h, 11)) == 3 * 11 + 1 + 6          # 40 packed digit rows: three tiles
+    _check(p, runner, engs, {"gemm1": 103, "gemm2": 11, "segmented": True}, blocks_per_call=3, with_exact=False)
 
 
 def test_c5_streaming_genie_gxe_at_n500k_vs_oracle():

@@ -156,6 +156,58 @@ def test_pass2_device_assembly_equals_materialised_torch_path(case):
         e_.close()
 
 
+@pytest.mark.parametrize("case", ["cov_3bins", "cov_q4_3bins", "cov_20bins", "dom_cov_8bins"])
+def test_pass2_float32_products_vs_float64_products_beyond_65536_samples(case):
+    """From 65 536 samples on pass 2's one-read kernel takes its float32 form by itself (PYRHE_OPT_DOTS_F32 = 2): float32
+    copies of the float64 whole-data rows, float32 partial sums over 128 elements, added in float64.  Held here against the
+    float64 form (dots_f32 = 0: the doubles go to the float64 matrix instruction unrounded) on the leave-one-out systems
+    themselves, at N = 70 000 -- the covariate shape (flat rows: the projections behind U = W Q W^T), quirk Q4's weighted
+    UXXz, the octet path of more than 16 block rows per batch element (20 bins) and 16 estimates (RHE_DOM with 8 bins):
+    T within 2e-7 of its largest entry per block, q alike, sigma^2 within 2e-6 and the jackknife SE within 1e-5 (advisor,
+    round 3: the only evidence had been one N = 500k configuration)."""
+    from pyrhe_amd import engine
+    from pyrhe_amd import estimate as est
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner, engine_capacity
+    dev = torch.device("cuda", 0)
+    nbin = int(case.rsplit("_", 1)[1][:-4])
+    n, m, jn, k = 70_000, 40 * nbin * 4, 4, 10
+    geno = engine.synth_genotypes(m, n, SEED, 19, dev)
+    rng = np.random.default_rng(21)
+    annot = np.zeros((m, nbin), np.int64)
+    annot[np.arange(m), np.arange(m) % nbin] = 1
+    plan = BlockPlan(annot, jn)
+    np.random.seed(0)
+    Z = np.random.randn(n, k)
+    g0 = synth.synth_rows(SEED, 19, 64, n)
+    mu = g0.mean(axis=1, keepdims=True)
+    y = ((g0 - mu) / np.sqrt(mu * (1 - mu / 2))).T @ rng.normal(0, 0.1, 64) + rng.normal(size=n)
+    y -= y.mean()
+    cov = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, 3))], axis=1)
+    kw = dict(n_orig=n, missing_indv=[], Z=Z, cov=cov, seed=0, streaming=True, compat="reference" if "q4" in case else "fixed",
+              dom=case.startswith("dom"))
+    out = {}
+    for f32 in (0, 2):
+        eng = engine.SketchEngine(n, n, engine_capacity(plan, n), device=dev)
+        eng.set_option("dots_f32", f32)
+        runner = SketchRunner(eng, geno, plan, (0, jn), **kw)
+        assert eng.n_pad >= 65536
+        sysm = runner.run_trait(y, check_missing=False)
+        sig = est.solve_all(sysm.T, sysm.q)
+        out[f32] = (sysm, sig[-1], np.asarray(est.jackknife_se(sig[:-1], jn)))
+        eng.close()
+    (a, sa, ea), (b, sb, eb) = out[0], out[2]
+    assert np.array_equal(a.M, b.M)
+    dT = np.abs(a.T - b.T).max(axis=(1, 2)) / np.abs(a.T).max(axis=(1, 2))
+    dq = np.abs(a.q - b.q).max(axis=tuple(range(1, a.q.ndim))) / np.abs(a.q).max(axis=tuple(range(1, a.q.ndim)))
+    floor = lambda v: np.maximum(np.abs(v), 0.05 * np.abs(v).max())
+    print(f"[{case}] float32 vs float64 products: T {dT.max():.1e}, q {dq.max():.1e}, sigma^2 {(np.abs(sa - sb) / floor(sa)).max():.1e}, "
+          f"SE {(np.abs(ea - eb) / floor(ea)).max():.1e}")
+    assert dT.max() > 0, "both runs took the same form: the option did not reach the kernel"
+    assert dT.max() <= 2e-7 and dq.max() <= 2e-7
+    assert (np.abs(sa - sb) / floor(sa)).max() <= 2e-6
+    assert (np.abs(ea - eb) / floor(ea)).max() <= 1e-5
+
+
 def test_full_sample_count_value_coding_segments_and_dots():
     """At N = 500 000 (the bench's row length, 32-bit offsets near their limits): value-coded == PLINK-coded results bit
     for bit; several bins in one call == one call per bin; pyrhe_engine_loo_dots over 10 x 500 736-element rows (all

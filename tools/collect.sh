@@ -1,13 +1,16 @@
 #!/bin/bash
-# Round-3 evidence at HEAD (run through gpurun from the repo root); tools/collect_r03_copy.py copies what is to be judged into
-# profiles/ afterwards (on the builder's side).
+# Evidence of one round at HEAD, run through gpurun from the repo root:  tools/collect.sh r04
+# tools/collect_copy.py r04 <commit> then copies what is to be judged from gpurun_out/r04_final (scratch) into profiles/ (tracked).
 #   1. rocprofv3 --kernel-trace --stats of the DEFAULT bench command (the driver's line) + the plain run
 #   2. PMC passes (own runs, one counter group each, --kernel-trace only) on a tenth of the cohort: headline, config 4, config 5
-#   3. the BASELINE configurations on one GPU + kernel traces of configs 4, 5, RHE_DOM;  4. the cross-check sweep
+#   3. the BASELINE configurations on one GPU + kernel traces of configs 2, 4, 5, RHE_DOM;  4. the cross-check sweep
+# (rocprofv3 is always given the program itself after `--`: no env / bash -c hop behind the profiler's preloaded library)
 set -e
+TAG=${1:?usage: tools/collect.sh <round tag, e.g. r04>}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/r03_final
-rm -rf $OUT && mkdir -p $OUT
+[ -f bench.py ] || { echo "not at the repo root"; exit 1; }
+OUT="gpurun_out/${TAG}_final"
+mkdir -p gpurun_out && rm -rf -- "./$OUT" && mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python3 bench.py --steps 3 --warmup 2 > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 echo "trace done"
 python3 bench.py --steps 3 --warmup 2 > $OUT/bench_plain.json 2> $OUT/bench_plain.err
