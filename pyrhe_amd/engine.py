@@ -127,42 +127,78 @@ def _require_gpu(device) -> torch.device:
     return device
 
 
-def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28, recode: Optional[str] = None) -> torch.Tensor:
+def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28, recode: Optional[str] = None,
+                  threads: Optional[int] = None, n_stage: int = 3, pitched: bool = True) -> torch.Tensor:
     """Host ``[m, ceil(N/4)]`` uint8 rows (a NumPy array or a memory-mapped ``.bed`` body) -> device ``[m, pitch]``,
-    zero padded.  The rows are never decoded on the host; they go through two pinned staging buffers of ``chunk_bytes``
-    (the host-side copy of piece i+1 overlaps the transfer of piece i), so a memory-mapped 100-GB file needs neither
-    100 GB of RAM nor one giant copy.  ``recode="value"``: every piece is recoded in place to the 2-bit value code
-    (``pyrhe_recode_rows``) on a second stream as soon as it has landed, WHILE the next piece crosses PCIe -- the one-time
-    transcode (51 ms per 125 GB of kernel time) then costs the load nothing but the last piece's 0.1 ms, where a recode after
-    the upload cost a single-trait run (one sketch pass of 46 ms) more than the 2 ms per pass it saves."""
+    zero padded.  The rows are never decoded on the host; they go through ``n_stage`` pinned staging buffers of ``chunk_bytes``
+    (the host-side copy of the next pieces overlaps the transfer of piece i), so a memory-mapped 100-GB file needs neither
+    100 GB of RAM nor one giant copy.  The host-side copy into a staging buffer is what bounds the load (one thread moves
+    10-12 GB/s, the link takes ~55): ``threads`` workers (default: up to 8 of the CPUs this process may use) each copy a
+    slice of the piece's rows (NumPy releases the GIL in the copy).  ``pitched``: the staging rows already carry the device
+    pitch (zero padding included), so every piece crosses PCIe as ONE contiguous copy instead of a 2-D copy of rows.
+    ``recode="value"``: every piece is recoded in place to the 2-bit value code (``pyrhe_recode_rows``) on a second stream as
+    soon as it has landed, WHILE the next piece crosses PCIe -- the one-time transcode (51 ms per 125 GB of kernel time) then
+    costs the load nothing but the last piece's 0.1 ms, where a recode after the upload cost a single-trait run (one sketch
+    pass of 46 ms) more than the 2 ms per pass it saves."""
+    from concurrent.futures import ThreadPoolExecutor
     device = _require_gpu(device)
     m, rb = packed_rows.shape
     pitch = (rb + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
-    out = torch.zeros((m, pitch), dtype=torch.uint8, device=device)
     if m == 0:
-        return out
-    rows_per = max(1, chunk_bytes // max(rb, 1))
-    staging = [torch.empty((min(rows_per, m), rb), dtype=torch.uint8).pin_memory() for _ in range(2 if m > rows_per else 1)]
-    done = [None, None]
-    with torch.cuda.device(device):
-        side = torch.cuda.Stream(device) if recode else None
-        for i, r0 in enumerate(range(0, m, rows_per)):
-            r1 = min(r0 + rows_per, m)
-            buf = staging[i % len(staging)]
-            if done[i % 2] is not None:
-                done[i % 2].synchronize()                     # the transfer that last used this buffer
-            buf[: r1 - r0].numpy()[...] = packed_rows[r0:r1]
-            out[r0:r1, :rb].copy_(buf[: r1 - r0], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            done[i % 2] = ev
+        return torch.zeros((0, pitch), dtype=torch.uint8, device=device)
+    sw = pitch if pitched else rb                                   # bytes per staged row
+    out = torch.empty((m, pitch), dtype=torch.uint8, device=device) if pitched else torch.zeros((m, pitch), dtype=torch.uint8, device=device)
+    rows_per = max(1, chunk_bytes // max(sw, 1))
+    n_pieces = -(-m // rows_per)
+    n_stage = max(1, min(int(n_stage), n_pieces))
+    staging = [torch.zeros((min(rows_per, m), sw), dtype=torch.uint8).pin_memory() for _ in range(n_stage)]     # (padding bytes stay zero)
+    if threads is None:
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        threads = max(1, min(8, avail))
+    threads = max(1, min(int(threads), rows_per))
+    pool = ThreadPoolExecutor(threads) if threads > 1 else None
+    done = [None] * n_stage
+
+    def fill(dst, r0, r1):
+        """rows r0 .. r1 - 1 of the source -> the first r1 - r0 staged rows"""
+        n = r1 - r0
+        if pool is None or n < 4 * threads:
+            dst[:n, :rb] = packed_rows[r0:r1]
+            return
+        step = -(-n // threads)
+        jobs = [pool.submit(lambda a=a: dst.__setitem__((slice(a, min(a + step, n)), slice(0, rb)), packed_rows[r0 + a:r0 + min(a + step, n)]))
+                for a in range(0, n, step)]
+        for j in jobs:
+            j.result()
+    try:
+        with torch.cuda.device(device):
+            side = torch.cuda.Stream(device) if recode else None
+            for i, r0 in enumerate(range(0, m, rows_per)):
+                r1 = min(r0 + rows_per, m)
+                buf = staging[i % n_stage]
+                if done[i % n_stage] is not None:
+                    done[i % n_stage].synchronize()               # the transfer that last used this buffer
+                fill(buf.numpy(), r0, r1)
+                if pitched:
+                    out[r0:r1].copy_(buf[: r1 - r0], non_blocking=True)
+                else:
+                    out[r0:r1, :rb].copy_(buf[: r1 - r0], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                done[i % n_stage] = ev
+                if recode:
+                    side.wait_event(ev)                           # the piece has landed
+                    with torch.cuda.stream(side):
+                        recode_rows(out[r0:r1], recode)
+            torch.cuda.current_stream(device).synchronize()
             if recode:
-                side.wait_event(ev)                           # the piece has landed (and `out` was zeroed before it)
-                with torch.cuda.stream(side):
-                    recode_rows(out[r0:r1], recode)
-        torch.cuda.current_stream(device).synchronize()
-        if recode:
-            side.synchronize()
+                side.synchronize()
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
     return out
 
 

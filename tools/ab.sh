@@ -21,11 +21,13 @@ while getopts "c:o:e:s:w:r:x:t:l:" f; do
   esac
 done
 [ ${#CONFIGS[@]} -eq 0 ] && CONFIGS=("C3"); [ ${#OPTS[@]} -eq 0 ] && OPTS=(""); [ ${#ENVS[@]} -eq 0 ] && ENVS=("")
-named() {
-  case "$1" in
-    C2) echo "--n-indv 50000 --n-snp 500000";; C3) echo "";; C4) echo "--n-bin 8 --n-cov 10";; C5) echo "--genie G+GxE";;
-    C5cov) echo "--genie G+GxE --n-cov 10";; DOM) echo "--dom";; DOMC4) echo "--dom --n-bin 8 --n-cov 10";;
-    RANK8) echo "--n-snp 130000 --jn 13";;      # rank 0's shard of an 8-GPU job: 13 of the 100 blocks
+named() {      # a configuration name, optionally followed by more bench.py arguments ("C2 --n-bin 8 --n-cov 10")
+  local first=${1%% *} rest=""
+  [ "$first" != "$1" ] && rest=" ${1#* }"
+  case "$first" in
+    C2) echo "--n-indv 50000 --n-snp 500000$rest";; C3) echo "$rest";; C4) echo "--n-bin 8 --n-cov 10$rest";; C5) echo "--genie G+GxE$rest";;
+    C5cov) echo "--genie G+GxE --n-cov 10$rest";; DOM) echo "--dom$rest";; DOMC4) echo "--dom --n-bin 8 --n-cov 10$rest";;
+    RANK8) echo "--n-snp 130000 --jn 13$rest";;      # rank 0's shard of an 8-GPU job: 13 of the 100 blocks
     *) echo "$1";;
   esac
 }
