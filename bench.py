@@ -290,12 +290,14 @@ def main():
         elif args.n_bin == 1 and not args.n_cov and args.genie == "G+GxE":
             shape = "G+GxE"
     try:
-        with open(os.path.join(REPO, "profiles", "r03_traffic.json")) as fh:
+        import glob
+        tfile = sorted(f for f in glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")) if "shapes" in json.load(open(f)))[-1]   # the latest round's
+        with open(tfile) as fh:
             tj = json.load(fh)
         kern = tj["shapes"][shape]["kernels"][dom_name] if shape else None
         if kern and N == tj["n_indv"] and M // jn == tj["block_snps"] and k == 10:
             traffic = int(kern["bytes_per_algorithmic_byte"] * bytes_per_launch)
-            traffic_source = (f"profiles/r03_traffic.json@{tj.get('commit', '?')} [{shape}]: separate --pmc passes at N={tj['n_indv']}, "
+            traffic_source = (f"profiles/{os.path.basename(tfile)}@{tj.get('commit', '?')} [{shape}]: separate --pmc passes at N={tj['n_indv']}, "
                               f"M={tj.get('n_snp', '?')}, jn={tj.get('jn', '?')}, ratio x this run's algorithmic bytes")
     except Exception:
         pass

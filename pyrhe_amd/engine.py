@@ -127,15 +127,44 @@ def _require_gpu(device) -> torch.device:
     return device
 
 
+_STAGING = {}        # pinned staging pieces kept between uploads: (rows per piece, bytes per staged row, pieces) -> tensors
+
+
+def _staging(rows_per: int, sw: int, n_stage: int):
+    """Pinned staging pieces, kept between calls: page-locking 2 x 256 MiB costs 0.1 s -- nothing once per cohort, a third of the
+    transfer time when a host-resident shard is uploaded window by window (HostRows).  One set at a time."""
+    key = (rows_per, sw, n_stage)
+    if key not in _STAGING:
+        _STAGING.clear()
+        _STAGING[key] = [torch.zeros((rows_per, sw), dtype=torch.uint8).pin_memory() for _ in range(n_stage)]
+    return _STAGING[key]
+
+
+def _file_backing(a: np.ndarray):
+    """``(path, byte offset of a[0, 0])`` when ``a`` is a C-contiguous view into a memory-mapped file (np.memmap), else None."""
+    if not isinstance(a, np.ndarray) or not a.flags.c_contiguous:
+        return None
+    root = a
+    while isinstance(getattr(root, "base", None), np.ndarray):
+        root = root.base
+    if not isinstance(root, np.memmap) or not getattr(root, "filename", None):
+        return None
+    off = int(root.offset) + (a.__array_interface__["data"][0] - root.__array_interface__["data"][0])
+    return str(root.filename), off
+
+
 def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28, recode: Optional[str] = None,
-                  threads: Optional[int] = None, n_stage: int = 3, pitched: bool = True) -> torch.Tensor:
+                  threads: Optional[int] = None, n_stage: int = 2, pitched: bool = False) -> torch.Tensor:
     """Host ``[m, ceil(N/4)]`` uint8 rows (a NumPy array or a memory-mapped ``.bed`` body) -> device ``[m, pitch]``,
-    zero padded.  The rows are never decoded on the host; they go through ``n_stage`` pinned staging buffers of ``chunk_bytes``
-    (the host-side copy of the next pieces overlaps the transfer of piece i), so a memory-mapped 100-GB file needs neither
-    100 GB of RAM nor one giant copy.  The host-side copy into a staging buffer is what bounds the load (one thread moves
-    10-12 GB/s, the link takes ~55): ``threads`` workers (default: up to 8 of the CPUs this process may use) each copy a
-    slice of the piece's rows (NumPy releases the GIL in the copy).  ``pitched``: the staging rows already carry the device
-    pitch (zero padding included), so every piece crosses PCIe as ONE contiguous copy instead of a 2-D copy of rows.
+    zero padded.  The rows are never decoded on the host; they go through ``n_stage`` pinned staging pieces of ``chunk_bytes``
+    (the host-side fill of piece i+1 overlaps the transfer of piece i), so a memory-mapped 100-GB file needs neither
+    100 GB of RAM nor one giant copy.  Measured on the MI355X box (tools/upload_rate.py, 8 GB): the link takes 24-25 GB/s from
+    pinned memory whatever fills the pieces -- one thread copying from an array in RAM already keeps up (24.4 GB/s; 2-16
+    threads, pitched staging rows, three or four pieces: 15-25 GB/s, the page-locking of more pieces costing more than it
+    gives).  What does NOT keep up is a memory-mapped FILE read through page faults (6-8 GB/s): rows that are a view of a
+    memory-mapped file are therefore read with ``os.preadv`` straight into the pinned piece, ``threads`` slices at a time
+    (default 4), and an array in RAM is copied by the same workers (NumPy releases the GIL in the copy).
+    ``pitched``: staging rows carry the device pitch (one contiguous copy per piece instead of a 2-D copy; arrays only).
     ``recode="value"``: every piece is recoded in place to the 2-bit value code (``pyrhe_recode_rows``) on a second stream as
     soon as it has landed, WHILE the next piece crosses PCIe -- the one-time transcode (51 ms per 125 GB of kernel time) then
     costs the load nothing but the last piece's 0.1 ms, where a recode after the upload cost a single-trait run (one sketch
@@ -146,24 +175,52 @@ def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28, r
     pitch = (rb + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
     if m == 0:
         return torch.zeros((0, pitch), dtype=torch.uint8, device=device)
+    backing = _file_backing(packed_rows)
+    if backing is not None:
+        pitched = False                                             # file bytes land as they lie: rows of rb bytes
     sw = pitch if pitched else rb                                   # bytes per staged row
     out = torch.empty((m, pitch), dtype=torch.uint8, device=device) if pitched else torch.zeros((m, pitch), dtype=torch.uint8, device=device)
-    rows_per = max(1, chunk_bytes // max(sw, 1))
+    rows_per = max(1, min(chunk_bytes // max(sw, 1), m))
     n_pieces = -(-m // rows_per)
     n_stage = max(1, min(int(n_stage), n_pieces))
-    staging = [torch.zeros((min(rows_per, m), sw), dtype=torch.uint8).pin_memory() for _ in range(n_stage)]     # (padding bytes stay zero)
+    staging = _staging(rows_per, sw, n_stage)
     if threads is None:
         try:
             avail = len(os.sched_getaffinity(0))
         except AttributeError:
             avail = os.cpu_count() or 1
-        threads = max(1, min(8, avail))
+        threads = max(1, min(4, avail))
     threads = max(1, min(int(threads), rows_per))
     pool = ThreadPoolExecutor(threads) if threads > 1 else None
     done = [None] * n_stage
+    fd = os.open(backing[0], os.O_RDONLY) if backing is not None else -1
+
+    def fill_file(dst, r0, r1):
+        """rows r0 .. r1 - 1 of the file -> the first (r1 - r0) * rb bytes of the piece, by positional reads"""
+        flat = dst.reshape(-1)
+        nbytes, base = (r1 - r0) * rb, backing[1] + r0 * rb
+
+        def read(a, b):
+            pos = a
+            while pos < b:
+                got = os.preadv(fd, [memoryview(flat[pos:b])], base + pos)
+                if got <= 0:
+                    raise IOError(f"{backing[0]}: short read at byte {base + pos}")
+                pos += got
+        step = -(-nbytes // threads) if pool is not None else nbytes
+        step = max(1 << 20, (step + 4095) // 4096 * 4096)
+        spans = [(a, min(a + step, nbytes)) for a in range(0, nbytes, step)]
+        if pool is None or len(spans) == 1:
+            for a, b in spans:
+                read(a, b)
+        else:
+            for j in [pool.submit(read, a, b) for a, b in spans]:
+                j.result()
 
     def fill(dst, r0, r1):
         """rows r0 .. r1 - 1 of the source -> the first r1 - r0 staged rows"""
+        if backing is not None:
+            return fill_file(dst, r0, r1)
         n = r1 - r0
         if pool is None or n < 4 * threads:
             dst[:n, :rb] = packed_rows[r0:r1]
@@ -180,7 +237,7 @@ def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28, r
                 r1 = min(r0 + rows_per, m)
                 buf = staging[i % n_stage]
                 if done[i % n_stage] is not None:
-                    done[i % n_stage].synchronize()               # the transfer that last used this buffer
+                    done[i % n_stage].synchronize()               # the transfer that last used this piece
                 fill(buf.numpy(), r0, r1)
                 if pitched:
                     out[r0:r1].copy_(buf[: r1 - r0], non_blocking=True)
@@ -190,16 +247,57 @@ def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28, r
                 ev.record()
                 done[i % n_stage] = ev
                 if recode:
-                    side.wait_event(ev)                           # the piece has landed
+                    side.wait_event(ev)                           # the piece has landed (and `out` was zeroed before it)
                     with torch.cuda.stream(side):
                         recode_rows(out[r0:r1], recode)
-            torch.cuda.current_stream(device).synchronize()
+            torch.cuda.current_stream(device).synchronize()       # (also: the cached pieces are free for the next call)
             if recode:
                 side.synchronize()
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
+        if fd >= 0:
+            os.close(fd)
     return out
+
+
+class HostRows:
+    """Genotype rows that STAY ON THE HOST (a NumPy array or the memory-mapped body of a ``.bed`` file) and reach the device a
+    window at a time -- for a shard that does not fit HBM beside the sketch store (N = 500k: more than ~2 M SNPs per GPU).
+    ``window(a, b)`` returns rows a .. b - 1 as a device ``[b - a, pitch]`` tensor in the coding ``recode`` names (uploaded
+    through :func:`upload_packed`: pinned staging, threaded host copies, the transcode overlapped); the most recent window is
+    kept, so a repeated or nested request costs nothing.  SketchRunner takes it in place of the resident device tensor: every
+    engine call then sketches one window (its blocks' rows), pass 2 works on the stored sketches and never asks for rows
+    again (unless it re-sketches: ``recompute_pass2``).  The pass is then bound by the PCIe link (~50 GB/s = 0.4 M SNPs/s at
+    N = 500k), not by HBM: a mode for cohorts that would otherwise not run at all, not a fast path."""
+
+    def __init__(self, host_rows: np.ndarray, device, recode: Optional[str] = "value"):
+        assert host_rows.ndim == 2 and host_rows.dtype == np.uint8
+        self.host = host_rows
+        self.device = _require_gpu(device)
+        self.recode = recode
+        m, rb = host_rows.shape
+        self.pitch = (rb + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
+        self.shape = (m, self.pitch)
+        self.dtype = torch.uint8
+        self._win = None
+        self.uploads = 0            # windows uploaded so far (tests, logs)
+        self.upload_bytes = 0
+
+    def window(self, a: int, b: int) -> torch.Tensor:
+        a, b = int(a), int(b)
+        assert 0 <= a <= b <= self.shape[0]
+        if self._win is not None and self._win[0] <= a and b <= self._win[1]:
+            return self._win[2][a - self._win[0]: b - self._win[0]]
+        self._win = None            # release the old window before the new one is allocated
+        t = upload_packed(self.host[a:b], self.device, recode=self.recode)
+        self._win = (a, b, t)
+        self.uploads += 1
+        self.upload_bytes += int(t.numel())
+        return t
+
+    def release(self):
+        self._win = None
 
 
 CODINGS = {"plink": 0, "value": 1}

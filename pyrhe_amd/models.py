@@ -39,7 +39,8 @@ class Base:
                  multiprocessing: bool = True, seed: Optional[int] = None, get_trace: bool = False,
                  trace_dir: Optional[str] = None, samp_prev: Optional[float] = None, pop_prev: Optional[float] = None,
                  log: Optional[Logger] = None, precision: str = "i8x3", compat: str = "reference",
-                 recompute_pass2: bool = False, sub_snps: int = 0, materialize_xxuz: bool = False):
+                 recompute_pass2: bool = False, sub_snps: int = 0, materialize_xxuz: bool = False,
+                 geno_resident: Optional[bool] = None):
         self.model = model
         self.materialize_xxuz = bool(materialize_xxuz)
         self.num_jack = self.num_blocks = int(num_jack)
@@ -136,7 +137,22 @@ class Base:
         r1 = self.plan.range(j1 - 1)[1] if j1 > j0 else 0
         # memmap slice -> HBM in pinned 256 MiB pieces; PLINK code -> allele counts in place, piece by piece on a second
         # stream while the next piece crosses PCIe: the transcode is hidden behind the load it belongs to
-        self.geno_dev = upload_packed(packed[r0:r1], self.device, recode="value")
+        # A shard that does not fit HBM (beside the sketch store and workspaces: more than 60 % of the free memory; N = 500k:
+        # beyond ~1.3 M SNPs per GPU) stays on the host and reaches the device one engine call's rows at a time
+        # (engine.HostRows): the pass is then bound by the PCIe link, but the cohort runs.  ``geno_resident`` /
+        # PYRHE_GENO_RESIDENT=0|1 force either form.
+        pitch = (packed.shape[1] + 255) // 256 * 256
+        if geno_resident is None and os.environ.get("PYRHE_GENO_RESIDENT") in ("0", "1"):
+            geno_resident = os.environ["PYRHE_GENO_RESIDENT"] == "1"
+        if geno_resident is None:
+            geno_resident = (r1 - r0) * pitch <= 0.6 * torch.cuda.mem_get_info(self.device)[0]
+        self.geno_resident = bool(geno_resident)
+        if self.geno_resident:
+            self.geno_dev = upload_packed(packed[r0:r1], self.device, recode="value")
+        else:
+            from .engine import HostRows
+            self.geno_dev = HostRows(packed[r0:r1], self.device, recode="value")
+            self.log._log(f"Genotypes stay on the host ({(r1 - r0) * pitch / 1e9:.1f} GB for this rank): streamed to the GPU per engine call")
         self._sub_snps = sub_snps
         self.engine = self._new_engine()
         self._engines = [self.engine]

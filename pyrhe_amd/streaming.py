@@ -454,17 +454,30 @@ class SketchRunner:
         raise KeyError((name, s0))
 
     # ---- imputation fill values ---------------------------------------------------------------
+    def _rows(self, a: int, b: int) -> torch.Tensor:
+        """Local rows a .. b - 1 on the device: a slice of the resident buffer, or a window uploaded from the host
+        (engine.HostRows: a shard that does not fit HBM)."""
+        g = self.geno
+        return g.window(a, b) if hasattr(g, "window") else g[a:b]
+
     def _block_rows(self, j: int) -> torch.Tensor:
         s, e = self.plan.range(j)
-        return self.geno[s - self.row0: e - self.row0]
+        return self._rows(s - self.row0, e - self.row0)
 
     def _ingest_stats(self):
-        """Per-SNP observed sums / missing counts of the local rows (one extra read, once per cohort)."""
+        """Per-SNP observed sums / missing counts of the local rows (one extra read, once per cohort; with host-resident
+        rows one extra pass over the link, in windows of one engine call's rows)."""
         if self._stats is None:
-            if self.geno.shape[0] == 0:          # a rank without local blocks (world > useful ranks)
+            m = self.geno.shape[0]
+            if m == 0:          # a rank without local blocks (world > useful ranks)
                 self._stats = (np.zeros(0, np.int64), np.zeros(0, np.int64))
                 return self._stats
-            s, nm = self.eng.block_stats(self.geno)
+            if hasattr(self.geno, "window"):
+                step = max(1, int(getattr(self.eng, "sub_snps", 0)) or self.plan.max_block)
+                parts = [self.eng.block_stats(self._rows(a, min(a + step, m))) for a in range(0, m, step)]
+                s, nm = torch.cat([p_[0] for p_ in parts]), torch.cat([p_[1] for p_ in parts])
+            else:
+                s, nm = self.eng.block_stats(self.geno)
             self._stats = (s.cpu().numpy().astype(np.int64), nm.cpu().numpy().astype(np.int64))
         return self._stats
 
@@ -727,7 +740,7 @@ class SketchRunner:
                     ent, offs = self._batch_entries(js)
                 s = self.plan.range(js[0])[0]
                 e = self.plan.range(js[-1])[1]
-                rows = self.geno[s - self.row0: e - self.row0]
+                rows = self._rows(s - self.row0, e - self.row0)
                 fill = None
                 if any_missing:
                     parts = []

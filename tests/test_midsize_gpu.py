@@ -56,6 +56,54 @@ def test_midsize_vs_oracle(precision, tol):
     eng.close()
 
 
+def test_host_resident_rows_in_windows_equal_resident_rows():
+    """engine.HostRows under the runner: 10 blocks in engine calls of 3 (a window of rows per call, four uploads per pass +
+    the statistics pass), 2 bins, missing calls (fill path), a keep mask -- the systems of the device-resident run bit for
+    bit, from a NumPy array in RAM and from a memory-mapped file (positional reads into the pinned staging pieces)."""
+    import os
+    import tempfile
+    from pyrhe_amd import engine
+    from pyrhe_amd.streaming import BlockPlan, SketchRunner
+    dev = torch.device("cuda", 0)
+    n, m, jn, k, nbin = 20000, 2000, 10, 10, 2
+    g = synth.synth_rows(SEED, 0, m, n).astype(np.int64)
+    rng = np.random.default_rng(4)
+    g[rng.random(g.shape) < 0.002] = -1                              # missing calls
+    packed = plink.encode_bed_rows(g)
+    y = rng.normal(size=n - 3)
+    y -= y.mean()
+    annot = np.zeros((m, nbin), np.int64)
+    annot[np.arange(m), np.arange(m) % nbin] = 1
+    plan = BlockPlan(annot, jn)
+    np.random.seed(0)
+    Z = np.random.randn(n - 3, k)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "w.bed")
+        with open(path, "wb") as fh:
+            fh.write(bytes([0x6C, 0x1B, 0x01]))
+            fh.write(packed.tobytes())
+        mm = np.memmap(path, dtype=np.uint8, mode="r", offset=3)[: packed.size].reshape(packed.shape)
+        out = {}
+        for tag in ("resident", "host array", "host file"):
+            eng = engine.SketchEngine(n, n - 3, plan.max_block * 3, precision="i8x3", device=dev)
+            eng.set_coding("value")
+            if tag == "resident":
+                geno = engine.upload_packed(packed, dev, recode="value")
+            else:
+                geno = engine.HostRows(packed if tag == "host array" else mm, dev, recode="value")
+            runner = SketchRunner(eng, geno, plan, (0, jn), n_orig=n, missing_indv=[5, 77, 19999], Z=Z, seed=0, streaming=True)
+            runner.row_limit = 3 * plan.max_block
+            sysm = runner.run_trait(y)
+            out[tag] = (sysm.T.copy(), sysm.q.copy(), sysm.M.copy())
+            if tag != "resident":
+                assert geno.uploads == 4 + 4, geno.uploads           # the statistics pass and the sketch pass, four windows of 600 rows each
+                assert eng.last_path()["gemm1"] > 0
+            eng.close()
+    for tag in ("host array", "host file"):
+        for a, b in zip(out["resident"], out[tag]):
+            assert np.array_equal(a, b), tag
+
+
 def test_linearity_and_block_additivity_at_bench_sample_count():
     """Size-independent properties at N = 500 000: the sketch is linear in the right-hand columns and additive over
     SNPs; exact integer genotype sums equal the popcount statistics kernel."""

@@ -93,6 +93,31 @@ def test_recompute_pass2_equals_stored_blocks(tmp_path):
     assert np.allclose(ra["sig_errs"], rb["sig_errs"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("name,cls,extra", [("rhe_3bin_cov", "RHE", {}), ("srhe_2bin_missing_cov", "StreamingRHE", {}),
+                                            ("srhe_2bin_missing_cov", "StreamingRHE", {"recompute_pass2": True}),
+                                            ("genie_gxe_cov", "GENIE", {"genie_model": "G+GxE"})])
+def test_host_resident_genotypes_equal_device_resident(name, cls, extra, tmp_path):
+    """``geno_resident=False`` (what a shard beyond HBM gets by itself): the packed rows stay in the memory-mapped .bed file and
+    reach the GPU one engine call's window at a time (engine.HostRows: positional reads into pinned staging, upload, transcode)
+    -- for the statistics pass, for every sketch call and for the re-sketch of ``recompute_pass2``.  Same bits as the
+    device-resident run, and the reference's results at 1e-5."""
+    z = load_golden(name)
+    if "genie_model" in extra:
+        c = fixtures.cohort_from_npz(z)
+        paths = fixtures.write_cohort_files(c, str(tmp_path))
+        extra = dict(extra, env_file=paths["env"])
+    a, _ = _run_model(z, tmp_path, cls, geno_resident=True, **extra)
+    b, _ = _run_model(z, tmp_path, cls, geno_resident=False, **extra)
+    assert a.geno_resident and not b.geno_resident and b.geno_dev.uploads == 0
+    ra, rb = a(trait=0), b(trait=0)
+    assert b.geno_dev.uploads >= 1
+    assert np.array_equal(a.systems.T, b.systems.T) and np.array_equal(a.systems.q, b.systems.q)
+    for k in ra:
+        assert np.array_equal(np.asarray(ra[k], float), np.asarray(rb[k], float), equal_nan=True), k
+    if cls != "GENIE":
+        _assert_dict(rb, z, 0, RESULT_KEYS_RHE)
+
+
 @pytest.mark.parametrize("name", ["rhe_3bin_cov", "rhe_1bin_missing", "rhe_1bin_n1024"])
 def test_i8x3_mode_matches_reference(name, tmp_path):
     """int8-limb GEMM 1 (two column tiles with covariates, missing-call fill path): same 1e-5 bound as f16x2."""
