@@ -206,6 +206,11 @@ int pyrhe_sum_blocks(const float* blocks, int n_blocks, int64_t block_stride, in
  * (pyrhe/src/models/rhe/streaming_rhe.py:18-21): sum_j U(sum_{i<=j} XXz_i) = U(sum_i (jn - i) XXz_i).   Asynchronous. */
 int pyrhe_sum_blocks_weighted(const float* blocks, int n_blocks, int64_t block_stride, int64_t n,
                               const double* weights, double* out, void* stream);
+/* Both of the above from ONE read of the blocks: out = the plain sum, out_weighted = the weighted one (the same additions in
+ * the same order as the two calls: same bits).  The reference-compatible streaming mode with covariates needs both, and the
+ * per-block store is 16 GB at 8 bins and N = 500k.   Asynchronous. */
+int pyrhe_sum_blocks_both(const float* blocks, int n_blocks, int64_t block_stride, int64_t n,
+                          const double* weights, double* out, double* out_weighted, void* stream);
 
 /*
  * Leave-one-out inner products for the normal equations: the Gram loops of Base.setup_lhs_rhs_jackknife

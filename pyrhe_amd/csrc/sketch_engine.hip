@@ -1254,6 +1254,16 @@ extern "C" int pyrhe_sum_blocks_weighted(const float* blocks, int n_blocks, int6
     return PYRHE_OK;
 }
 
+extern "C" int pyrhe_sum_blocks_both(const float* blocks, int n_blocks, int64_t block_stride, int64_t n,
+                                     const double* weights, double* out, double* out_weighted, void* stream_) {
+    if (!blocks || !out || !weights || !out_weighted) return fail(PYRHE_EINVAL, "NULL argument");
+    if (n <= 0 || n % 4 || block_stride % 4) return fail(PYRHE_EINVAL, "n and block_stride must be positive multiples of 4");
+    if (n_blocks < 0) return fail(PYRHE_EINVAL, "n_blocks negative");
+    sum_blocks_both_kernel<<<4096, 256, 0, (hipStream_t)stream_>>>(blocks, n_blocks, block_stride, n / 4, out, weights, out_weighted);
+    HIPCHK(hipGetLastError());
+    return PYRHE_OK;
+}
+
 extern "C" int pyrhe_engine_loo_dots(pyrhe_engine_t* e, const pyrhe_row_t* x, int nx, const pyrhe_row_t* y, int ny,
                                      int64_t period, int n_sub, int n_batch, double* out, void* stream_) {
     if (!e || !x || !y || !out) return fail(PYRHE_EINVAL, "NULL argument");

@@ -48,6 +48,7 @@ SYMBOLS = {
     "pyrhe_engine_set_coding": (_i32, [_vp, _i32]),
     "pyrhe_sum_blocks": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
     "pyrhe_sum_blocks_weighted": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _vp]),
+    "pyrhe_sum_blocks_both": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp]),
     "pyrhe_engine_loo_dots": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "pyrhe_engine_loo_dots_multi": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pyrhe_engine_apply_projector": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp]),
@@ -377,6 +378,25 @@ def sum_blocks(blocks: torch.Tensor, weights: Optional[torch.Tensor] = None) -> 
     return out
 
 
+def sum_blocks_both(blocks: torch.Tensor, weights: torch.Tensor):
+    """The plain and the weighted float64 sum over the first dimension of ``blocks [jl, ...]`` from ONE read of them
+    (``pyrhe_sum_blocks_both``); returns ``(sum, weighted sum)``, the same bits as the two :func:`sum_blocks` calls."""
+    _require_gpu(blocks.device)
+    assert blocks.dtype == torch.float32 and blocks.is_contiguous()
+    assert weights.dtype == torch.float64 and weights.is_contiguous() and weights.numel() == blocks.shape[0]
+    out = torch.zeros(blocks.shape[1:], dtype=torch.float64, device=blocks.device)
+    out_w = torch.zeros_like(out)
+    if blocks.shape[0] == 0:
+        return out, out_w
+    n = blocks[0].numel()
+    if n % 4:
+        raise ValueError("sum_blocks_both: the block size must be a multiple of 4 elements")
+    with torch.cuda.device(blocks.device):
+        _check(load_library().pyrhe_sum_blocks_both(_ptr(blocks), blocks.shape[0], n, n, _ptr(weights), _ptr(out), _ptr(out_w),
+                                                    _stream_ptr(blocks.device)), "pyrhe_sum_blocks_both")
+    return out, out_w
+
+
 def decode_rows(packed: torch.Tensor) -> torch.Tensor:
     """Dense float32 ``[m, 4*pitch]`` decode of packed rows (NaN = missing call)."""
     lib = load_library()
@@ -529,6 +549,10 @@ class SketchEngine:
                                                           _ptr(out_norm_dom), 1 if accumulate else 0, _stream_ptr(self.device)),
                    "pyrhe_engine_sketch_block_dom")
         return out_sketch, out_norm, out_sketch_dom, out_norm_dom
+
+    def sum_blocks_both(self, blocks: torch.Tensor, weights: torch.Tensor):
+        """(plain, weighted) float64 sums over the block dimension from one read of the store."""
+        return sum_blocks_both(blocks, weights)
 
     def sum_blocks(self, blocks: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Float64 (weighted) sum over the stored per-block sketches (the reference's ``aggregate``)."""

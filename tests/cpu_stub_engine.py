@@ -144,6 +144,9 @@ class CpuStubEngine:
             return out
         return torch.einsum("zal,zbl->zab", mat(x), mat(y))
 
+    def sum_blocks_both(self, blocks, weights):
+        return self.sum_blocks(blocks), self.sum_blocks(blocks, weights)
+
     def sum_blocks(self, blocks, weights=None):
         """Oracle-side twin of pyrhe_sum_blocks[_weighted]."""
         if not blocks.shape[0]:

@@ -665,6 +665,21 @@ def test_many_short_lists_share_one_gemm1_launch(dev, k, dom):
     eng.close()
 
 
+def test_sum_blocks_both_equals_the_two_single_sums(dev):
+    """pyrhe_sum_blocks_both: the plain and the weighted float64 block sums from one read of the store -- the bits of
+    pyrhe_sum_blocks and pyrhe_sum_blocks_weighted (same additions, same order), also on a slice of the store and on none."""
+    from pyrhe_amd import engine
+    g = torch.Generator().manual_seed(3)
+    store = torch.randn((7, 3, 5, 1024), generator=g, dtype=torch.float32).to(dev)
+    w = torch.arange(9, 2, -1, dtype=torch.float64, device=dev)
+    for a, b in ((0, 7), (2, 5), (3, 3)):
+        plain, weighted = engine.sum_blocks_both(store[a:b], w[a:b].contiguous())
+        assert torch.equal(plain, engine.sum_blocks(store[a:b]))
+        assert torch.equal(weighted, engine.sum_blocks(store[a:b], w[a:b].contiguous()))
+    ref = (store.double() * w.reshape(-1, 1, 1, 1)).sum(dim=0)
+    assert torch.allclose(engine.sum_blocks_both(store, w)[1], ref, rtol=1e-14, atol=0)
+
+
 def test_stream_read_measures_a_bandwidth_and_rejects_bad_buffers(dev):
     """pyrhe_stream_read, bench.py's measuring stick (the box's measured stream bandwidth beside the nominal peak)."""
     from pyrhe_amd import engine
