@@ -1133,7 +1133,9 @@ class SketchRunner:
             if self.dom:
                 tot_crd = [b[:jl].sum(dim=0) for b in self.blocks_crd]
             # Block sums as ONE float64 reduction over the stored per-block sketches per bucket (the reference adds the
-            # blocks one by one in float64, base.py:468-471; any order agrees to 1e-16).  U is linear, so the "fixed" UXXz
+            # blocks one by one in float64, base.py:468-471; any order agrees to 1e-16).  (Round 4 measured the alternative --
+            # the sums of groups of calls on a side stream beside the next calls' contractions: 8 bins + covariates 55.0 ->
+            # 57.4 ms per pass, headline 45.6 -> 46.4: a third stream of reads slows GEMM 1 by more than the sums take.)  U is linear, so the "fixed" UXXz
             # total is U applied to the total (float32 rounding order differs from per-block application at 1e-7).
             zeros_like_tot = lambda b: torch.zeros(b.shape[1:], dtype=f64, device=dev)
             sum_blocks = lambda b: self.eng.sum_blocks(b) if b.shape[2] else zeros_like_tot(b)     # (a pass without sketch columns)
