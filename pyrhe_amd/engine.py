@@ -268,8 +268,9 @@ class HostRows:
     ``window(a, b)`` returns rows a .. b - 1 as a device ``[b - a, pitch]`` tensor in the coding ``recode`` names (uploaded
     through :func:`upload_packed`: pinned staging, threaded host copies, the transcode overlapped); the most recent window is
     kept, so a repeated or nested request costs nothing.  SketchRunner takes it in place of the resident device tensor: every
-    engine call then sketches one window (its blocks' rows), pass 2 works on the stored sketches and never asks for rows
-    again (unless it re-sketches: ``recompute_pass2``).  The pass is then bound by the PCIe link (~50 GB/s = 0.4 M SNPs/s at
+    engine call then sketches one window (its blocks' rows) -- the per-SNP statistics behind the imputation are taken from
+    the same window right before its sketch, not in a pass over the link of their own --, pass 2 works on the stored sketches
+    and never asks for rows again (unless it re-sketches: ``recompute_pass2``).  The pass is then bound by the PCIe link (~50 GB/s = 0.4 M SNPs/s at
     N = 500k), not by HBM: a mode for cohorts that would otherwise not run at all, not a fast path."""
 
     def __init__(self, host_rows: np.ndarray, device, recode: Optional[str] = "value"):

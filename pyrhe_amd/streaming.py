@@ -481,6 +481,33 @@ class SketchRunner:
             self._stats = (s.cpu().numpy().astype(np.int64), nm.cpu().numpy().astype(np.int64))
         return self._stats
 
+    # ---- host-resident rows: statistics and fill values window by window, inside the first sketch pass -----------------
+    def _lazy_begin(self, pass_index: int):
+        m = self.geno.shape[0]
+        self._stats_lazy = (np.zeros(m, np.int64), np.zeros(m, np.int64))
+        self._lazy_draw = self._uniform_stream(pass_index)
+        if not hasattr(self, "_fills"):
+            self._fills = {}
+        self._fills[pass_index] = [None] * (self.j1 - self.j0)
+
+    def _lazy_window_stats(self, pass_index: int, js, rows: torch.Tensor):
+        """Statistics of one call's window ``rows`` (the blocks ``js``) and the fill values of those blocks."""
+        a = self.plan.range(js[0])[0] - self.row0
+        s_, nm_ = self.eng.block_stats(rows)
+        self._stats_lazy[0][a:a + rows.shape[0]] = s_.cpu().numpy()
+        self._stats_lazy[1][a:a + rows.shape[0]] = nm_.cpu().numpy()
+        self._stats, keep = self._stats_lazy, self._stats          # (_fill_for_block reads the arrays through _ingest_stats)
+        try:
+            for j in js:
+                sj, ej = self.plan.range(j)
+                self._fills[pass_index][j - self.j0] = self._fill_for_block(j, self._lazy_draw(j, ej - sj))
+        finally:
+            self._stats = keep
+
+    def _lazy_end(self):
+        self._stats = self._stats_lazy
+        del self._stats_lazy, self._lazy_draw
+
     def _fill_for_block(self, j: int, uniforms: Optional[np.ndarray]) -> Optional[torch.Tensor]:
         sums, nmiss = self._ingest_stats()
         s, e = self.plan.range(j)
@@ -720,8 +747,16 @@ class SketchRunner:
         outputs of engine pass p (``[nbin, n_sketch_p, n_pad]`` float32 / ``[nbin, n_norm_p]`` float64).  With a
         one-slot store (``recompute_pass2``) every block lands in slot 0 and ``after_block(jl_index, j)`` consumes it;
         ``after_call(jl0, n)`` runs behind every engine call of the stored form (local blocks jl0 .. jl0 + n - 1 are enqueued)."""
-        any_missing = bool(self._check_missing and self._ingest_stats()[1].any())
-        block_fills = self._block_fills(pass_index) if any_missing else None
+        # Host-resident rows (engine.HostRows) whose statistics are not known yet: no pass over the link of their own -- every
+        # call's window gets its statistics (one HBM-speed kernel) and, from them, the fill values of its blocks right before
+        # its sketch; the imputation stream is consumed in block order either way (_lazy_window_stats)
+        lazy = bool(self._check_missing and self._stats is None and hasattr(self.geno, "window") and self.geno.shape[0] > 0)
+        if lazy:
+            self._lazy_begin(pass_index)
+            any_missing, block_fills = True, self._fills[pass_index]
+        else:
+            any_missing = bool(self._check_missing and self._ingest_stats()[1].any())
+            block_fills = self._block_fills(pass_index) if any_missing else None
         one_slot = after_block is not None
         pipelined = [] if one_slot else [eng for eng in self.engs if hasattr(eng, "set_async")]
         for eng in pipelined:
@@ -741,6 +776,8 @@ class SketchRunner:
                 s = self.plan.range(js[0])[0]
                 e = self.plan.range(js[-1])[1]
                 rows = self._rows(s - self.row0, e - self.row0)
+                if lazy:
+                    self._lazy_window_stats(pass_index, js, rows)
                 fill = None
                 if any_missing:
                     parts = []
@@ -804,6 +841,8 @@ class SketchRunner:
                     for eng in pipelined:
                         eng.join()         # (a no-op unless the engine runs its private two-stream pipeline)
                     after_call(jl0, len(js))
+            if lazy:
+                self._lazy_end()
         finally:
             for eng in pipelined:
                 eng.join()

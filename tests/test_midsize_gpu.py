@@ -57,8 +57,8 @@ def test_midsize_vs_oracle(precision, tol):
 
 
 def test_host_resident_rows_in_windows_equal_resident_rows():
-    """engine.HostRows under the runner: 10 blocks in engine calls of 3 (a window of rows per call, four uploads per pass +
-    the statistics pass), 2 bins, missing calls (fill path), a keep mask -- the systems of the device-resident run bit for
+    """engine.HostRows under the runner: 10 blocks in engine calls of 3 (a window of rows per call, four uploads per pass, the
+    per-SNP statistics taken from the same windows), 2 bins, missing calls (fill path), a keep mask -- the systems of the device-resident run bit for
     bit, from a NumPy array in RAM and from a memory-mapped file (positional reads into the pinned staging pieces)."""
     import os
     import tempfile
@@ -96,7 +96,7 @@ def test_host_resident_rows_in_windows_equal_resident_rows():
             sysm = runner.run_trait(y)
             out[tag] = (sysm.T.copy(), sysm.q.copy(), sysm.M.copy())
             if tag != "resident":
-                assert geno.uploads == 4 + 4, geno.uploads           # the statistics pass and the sketch pass, four windows of 600 rows each
+                assert geno.uploads == 4, geno.uploads               # four windows of 600 rows; their statistics (missing calls) are taken from the same windows
                 assert eng.last_path()["gemm1"] > 0
             eng.close()
     for tag in ("host array", "host file"):
