@@ -134,11 +134,11 @@ _STAGING = {}        # pinned staging pieces kept between uploads: (rows per pie
 def _staging(rows_per: int, sw: int, n_stage: int):
     """Pinned staging pieces, kept between calls: page-locking 2 x 256 MiB costs 0.1 s -- nothing once per cohort, a third of the
     transfer time when a host-resident shard is uploaded window by window (HostRows).  One set at a time."""
-    key = (rows_per, sw, n_stage)
-    if key not in _STAGING:
+    have = _STAGING.get("pieces")
+    if have is None or have[0].shape[1] != sw or have[0].shape[0] < rows_per or len(have) < n_stage:
         _STAGING.clear()
-        _STAGING[key] = [torch.zeros((rows_per, sw), dtype=torch.uint8).pin_memory() for _ in range(n_stage)]
-    return _STAGING[key]
+        _STAGING["pieces"] = have = [torch.zeros((rows_per, sw), dtype=torch.uint8).pin_memory() for _ in range(n_stage)]
+    return [t[:rows_per] for t in have[:n_stage]]          # (a smaller request -- the last window of a shard -- takes views)
 
 
 def _file_backing(a: np.ndarray):
@@ -181,6 +181,9 @@ def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28, r
         pitched = False                                             # file bytes land as they lie: rows of rb bytes
     sw = pitch if pitched else rb                                   # bytes per staged row
     out = torch.empty((m, pitch), dtype=torch.uint8, device=device) if pitched else torch.zeros((m, pitch), dtype=torch.uint8, device=device)
+    # a small upload (one window of a host-resident shard: a few hundred MB) goes in about eight pieces, so that the fill of a
+    # piece overlaps the transfer of the one before it inside the window too
+    chunk_bytes = max(min(chunk_bytes, 32 << 20), min(chunk_bytes, (m * sw + 7) // 8))
     rows_per = max(1, min(chunk_bytes // max(sw, 1), m))
     n_pieces = -(-m // rows_per)
     n_stage = max(1, min(int(n_stage), n_pieces))
