@@ -177,3 +177,29 @@ def test_solve_all_equals_per_system_qr_and_keeps_error_behaviour():
         assert np.allclose(est.solve_all(T, q, "lstsq"), ref, rtol=1e-8)
     with pytest.raises(np.linalg.LinAlgError):
         est.solve_all(np.zeros((3, 2, 2)), np.ones((3, 2)))
+
+
+def test_annot_fast_reader_equals_the_reference_line_loop(tmp_path):
+    """read_annot parses a plain annotation file with pandas' C reader and everything else with the reference's own line loop
+    (file_processing.py:37-69): same matrix, dtype and counts on a plain file, with '#' lines, with one column; lines the C
+    reader does not take (trailing spaces) fall through to the loop; a blank line raises as it does in the reference."""
+    from pyrhe_amd import io as rio
+    rng = np.random.default_rng(0)
+    mat = np.zeros((500, 5), np.int64)
+    mat[np.arange(500), rng.integers(0, 5, 500)] = 1
+    mat[::7, 2] = 1                                                   # overlapping annotations
+    body = ["# header comment"] + [" ".join(str(v) for v in row) for row in mat]
+    body.insert(100, "# a comment in the middle")
+    cases = {"plain": "\n".join(body[1:100] + body[101:]) + "\n", "comments": "\n".join(body) + "\n",
+             "one_column": "\n".join(str(v) for v in mat[:, 0]) + "\n",
+             "trailing_spaces": "\n".join(l + " " for l in body[1:100]) + "\n"}
+    for name, text in cases.items():
+        p = tmp_path / (name + ".annot")
+        p.write_text(text)
+        a, b = rio.read_annot(str(p)), rio._read_annot_lines(str(p))
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[1].dtype == b[1].dtype and np.array_equal(a[2], b[2]), name
+    assert np.array_equal(rio.read_annot(str(tmp_path / "comments.annot"))[1], mat)
+    p = tmp_path / "blank.annot"
+    p.write_text("1 0\n\n0 1\n")
+    with pytest.raises(ValueError):
+        rio.read_annot(str(p))
