@@ -128,7 +128,7 @@ def _require_gpu(device) -> torch.device:
     return device
 
 
-_STAGING = {}        # pinned staging pieces kept between uploads: (rows per piece, bytes per staged row, pieces) -> tensors
+_STAGING = {}        # "pieces": the pinned staging pieces kept between uploads (one set; re-made when a call needs wider or more rows)
 
 
 def _staging(rows_per: int, sw: int, n_stage: int):
@@ -159,12 +159,13 @@ def upload_packed(packed_rows: np.ndarray, device, chunk_bytes: int = 1 << 28, r
     """Host ``[m, ceil(N/4)]`` uint8 rows (a NumPy array or a memory-mapped ``.bed`` body) -> device ``[m, pitch]``,
     zero padded.  The rows are never decoded on the host; they go through ``n_stage`` pinned staging pieces of ``chunk_bytes``
     (the host-side fill of piece i+1 overlaps the transfer of piece i), so a memory-mapped 100-GB file needs neither
-    100 GB of RAM nor one giant copy.  Measured on the MI355X box (tools/upload_rate.py, 8 GB): the link takes 24-25 GB/s from
-    pinned memory whatever fills the pieces -- one thread copying from an array in RAM already keeps up (24.4 GB/s; 2-16
-    threads, pitched staging rows, three or four pieces: 15-25 GB/s, the page-locking of more pieces costing more than it
-    gives).  What does NOT keep up is a memory-mapped FILE read through page faults (6-8 GB/s): rows that are a view of a
-    memory-mapped file are therefore read with ``os.preadv`` straight into the pinned piece, ``threads`` slices at a time
-    (default 4), and an array in RAM is copied by the same workers (NumPy releases the GIL in the copy).
+    100 GB of RAM nor one giant copy.  Measured on the MI355X box (tools/upload_rate.py, 8 GB): with the staging
+    pieces KEPT between calls (_staging: page-locking them anew on every call was 0.1 s of a 0.33 s upload) the link takes
+    48-54 GB/s from an array in RAM -- 24-25 before --, filled by ``threads`` workers (default 4; NumPy releases the GIL in the
+    copy).  A memory-mapped FILE read through page faults fed it at 6-8 GB/s: rows that are a view of a mapped file are
+    therefore read with ``os.preadv`` straight into the pinned piece, ``threads`` slices at a time: 36-42 GB/s (page cache warm).
+    An upload of a few hundred MB (one window of a host-resident shard) goes in about eight pieces, so that fills and transfers
+    overlap inside it as well.
     ``pitched``: staging rows carry the device pitch (one contiguous copy per piece instead of a 2-D copy; arrays only).
     ``recode="value"``: every piece is recoded in place to the 2-bit value code (``pyrhe_recode_rows``) on a second stream as
     soon as it has landed, WHILE the next piece crosses PCIe -- the one-time transcode (51 ms per 125 GB of kernel time) then
@@ -273,8 +274,9 @@ class HostRows:
     kept, so a repeated or nested request costs nothing.  SketchRunner takes it in place of the resident device tensor: every
     engine call then sketches one window (its blocks' rows) -- the per-SNP statistics behind the imputation are taken from
     the same window right before its sketch, not in a pass over the link of their own --, pass 2 works on the stored sketches
-    and never asks for rows again (unless it re-sketches: ``recompute_pass2``).  The pass is then bound by the PCIe link (~50 GB/s = 0.4 M SNPs/s at
-    N = 500k), not by HBM: a mode for cohorts that would otherwise not run at all, not a fast path."""
+    and never asks for rows again (unless it re-sketches: ``recompute_pass2``).  The pass is then bound by the PCIe link
+    (36-53 GB/s = 0.3-0.4 M SNPs/s at N = 500k), not by HBM: a mode for cohorts that would otherwise not run at all, not a
+    fast path."""
 
     def __init__(self, host_rows: np.ndarray, device, recode: Optional[str] = "value"):
         assert host_rows.ndim == 2 and host_rows.dtype == np.uint8
