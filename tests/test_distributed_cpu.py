@@ -96,7 +96,7 @@ def test_streaming_q4_weighted_form_close_to_sequential(tmp_path):
 # More ranks than the golden fixtures exercise: uneven shards (jn = 100 over 8 ranks: 13, ..., 13, 9), ranks without a
 # block (world > jn), covariates with the reference-compatible (weighted) UXXz -- all against the one-process run.
 # ----------------------------------------------------------------------------------------------------------------------
-def _synth_runner(n, m, jn, nbin, with_cov, compat, blocks_per_call=0):
+def _synth_runner(n, m, jn, nbin, with_cov, compat, blocks_per_call=0, dom=False):
     from oracle import fixtures
     from oracle import rhe_oracle as O
     from pyrhe_amd.streaming import BlockPlan, SketchRunner, shard_ranges
@@ -114,7 +114,7 @@ def _synth_runner(n, m, jn, nbin, with_cov, compat, blocks_per_call=0):
     geno[:, : c.packed.shape[1]] = torch.from_numpy(c.packed[r0:r1].copy())
     Z = O.make_probe_vectors(0, n, 4)
     runner = SketchRunner(eng, geno, plan, (j0, j1), n_orig=n, missing_indv=[], Z=Z, cov=c.cov, seed=0, streaming=True,
-                          compat=compat)
+                          compat=compat, dom=bool(dom))
     if blocks_per_call:          # several engine calls per rank: one round of collectives per call (SketchRunner.pass1)
         runner.row_limit = blocks_per_call * plan.max_block
     return runner, y, (j0, j1)
@@ -144,7 +144,10 @@ def _synth_worker(rank, world, port, shape, out_dir):
                                          (4, (64, 90, 3, 2, 2, "fixed", 1)),          # a rank without blocks in a 1-round exchange
                                          # 50 blocks per rank in calls of 2 = 25 calls: grouped into 4 rounds of 7, 7, 7, 4 calls
                                          # (SketchRunner.MAX_EXCHANGE_ROUNDS: buffers and wire bytes do not grow with the calls)
-                                         (2, (96, 300, 100, 2, 3, "reference", 2))])
+                                         (2, (96, 300, 100, 2, 3, "reference", 2)),
+                                         # RHE_DOM with covariates in the reference-compatible mode: plain and (jn - j)-weighted
+                                         # partial totals of both encodings from one read per round (sum_blocks_both)
+                                         (3, (64, 120, 10, 2, 2, "reference", 2, True))])
 def test_many_ranks_uneven_and_empty_shards_equal_one_rank(world, shape, tmp_path):
     from pyrhe_amd.streaming import shard_ranges
     mp.spawn(_synth_worker, args=(world, _free_port(), shape, str(tmp_path)), nprocs=world, join=True)
@@ -157,6 +160,8 @@ def test_many_ranks_uneven_and_empty_shards_equal_one_rank(world, shape, tmp_pat
         assert np.array_equal(parts[0]["T"], p["T"]) and np.array_equal(parts[0]["q"], p["q"])     # every rank holds all systems
     from pyrhe_amd.streaming import SketchRunner
     per_call = shape[6] if len(shape) > 6 else None
+    if len(shape) > 7 and shape[7]:
+        per_call = 1                 # RHE_DOM on the stand-in engine: one block per call (the segmented flow is the int8 engine's)
     if per_call:
         calls = -(-max(sizes) // per_call)
         want = -(-calls // -(-calls // SketchRunner.MAX_EXCHANGE_ROUNDS))
